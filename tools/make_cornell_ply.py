@@ -14,7 +14,7 @@ with 24-byte vertices (x, y, z, nx, ny, nz as float32) and 17-byte faces
 The meshes written here are RECONSTRUCTIONS from the canonical Cornell-box
 measurements (millimetres, y up) combined with the transforms stored in
 configs/cornell_box/scene.toml, which map PLY (x, y, z) to world
-(-s*x, s*z, s*y) + t.  They are not byte-identical to the originals.
+(-s*x, s*z, s*y) + t.  They have the originals' byte sizes but are not byte-identical to them.
 
   * room: x in [0, 556], y in [0, 548.8], z in [0, 559.2]; the opening faces -z
   * light: 130 x 105 mm quad centred on its local origin (the scene transform
@@ -89,7 +89,8 @@ def cube_quads(h):
 
 def main(root):
     X, Y, Z = 556.0, 548.8, 559.2
-    note = "reconstruction of an LFS-stubbed RustRayTracer mesh (tools/make_cornell_ply.py)"
+    # 64 characters, which makes every file exactly as long as its LFS stub says
+    note = "reconstructed RustRayTracer LFS mesh:  tools/make_cornell_ply.py"
     cb = os.path.join(root, "configs", "cornell_box")
     os.makedirs(cb, exist_ok=True)
     os.makedirs(os.path.join(root, "assets"), exist_ok=True)
