@@ -89,8 +89,8 @@ def cube_quads(h):
 
 def main(root):
     X, Y, Z = 556.0, 548.8, 559.2
-    # 64 characters, which makes every file exactly as long as its LFS stub says
-    note = "reconstructed RustRayTracer LFS mesh:  tools/make_cornell_ply.py"
+    # 63 characters, which makes every file exactly as long as its LFS stub says
+    note = "reconstructed RustRayTracer LFS mesh: tools/make_cornell_ply.py"
     cb = os.path.join(root, "configs", "cornell_box")
     os.makedirs(cb, exist_ok=True)
     os.makedirs(os.path.join(root, "assets"), exist_ok=True)
