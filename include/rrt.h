@@ -1,0 +1,208 @@
+/*
+ * rrt.h - C ABI of the MI355X (gfx950) path-tracing backend.
+ *
+ * The reference renderer (nero19960329/RustRayTracer) has no FFI of its own:
+ * its only seam is the Rust function
+ *     pub fn render(config: &RenderConfig, scene: &Scene) -> RgbImage     (src/renderer.rs:73)
+ * called once from main (src/main.rs:48).  The entry points below are what a
+ * Rust `extern "C"` block for that seam would bind: a flattened,
+ * transform-baked scene goes in, radiance sums / 8-bit pixels come out.
+ * Every entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns RRT_OK (0) or a negative rrt_status; nothing
+ *     throws or aborts across the boundary; rrt_last_error() returns a
+ *     thread-local message for the last failure on the calling thread
+ *   - all arithmetic inputs are f64, as in the reference (src/math.rs:4-8);
+ *     the device computes in f32 or f64 as rrt_render_desc.precision says
+ *   - handles are not thread-safe; one host thread drives one backend
+ *   - pointers named *_dev_or_host may be device or host memory; the library
+ *     asks the HIP runtime which one it was given
+ */
+#ifndef RRT_H
+#define RRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rrt_status {
+    RRT_OK = 0,
+    RRT_ERR_INVALID = -1,     /* bad argument / config the reference would panic on */
+    RRT_ERR_HIP = -2,         /* a HIP runtime call failed */
+    RRT_ERR_UNSUPPORTED = -3, /* valid request this build cannot serve */
+    RRT_ERR_NO_DEVICE = -4,   /* no usable gfx950 device */
+    RRT_ERR_IO = -5,          /* file could not be read / written / parsed */
+    RRT_ERR_NOMEM = -6
+} rrt_status;
+
+/* src/shapes/shape.rs:16-24 (a Mesh is flattened into its faces). */
+typedef enum rrt_prim_type {
+    RRT_PRIM_SPHERE = 0,   /* v[0..2] centre, v[3] radius                 src/shapes/sphere.rs:12-15 */
+    RRT_PRIM_PLANE = 1,    /* v[0..2] point, v[3..5] unit normal          src/shapes/plane.rs:12-15 */
+    RRT_PRIM_TRIANGLE = 2, /* v[0..8] three vertices                      src/shapes/triangle.rs:12-14 */
+    RRT_PRIM_QUAD = 3      /* v[0..11] four vertices                      src/shapes/quadrilateral.rs:13-15 */
+} rrt_prim_type;
+
+/* src/material.rs:286-294 */
+typedef enum rrt_material_type {
+    RRT_MAT_EMISSIVE = 0,   /* rgb = emitted colour                                          */
+    RRT_MAT_LAMBERTIAN = 1, /* rgb = albedo                                                  */
+    RRT_MAT_PHONG = 2,      /* rgb = specular, param = shininess                             */
+    RRT_MAT_REFLECTOR = 3,  /* no parameters                                                 */
+    RRT_MAT_DIELECTRIC = 4  /* param = index of refraction                                   */
+} rrt_material_type;
+
+/* src/sampler.rs:168-173 */
+typedef enum rrt_sampler_type { RRT_SAMPLER_RANDOM = 0, RRT_SAMPLER_STRATIFIED = 1 } rrt_sampler_type;
+
+typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_precision;
+
+/* How closest-hit walks the primitives.  AUTO = wave-uniform linear scan for
+ * small scenes, LBVH (+ linear scan of the unbounded planes) otherwise. */
+typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2 } rrt_accel;
+
+/* Which kernel organisation renders.  FUSED keeps a path in registers for
+ * all of its bounces and refills finished lanes with new camera samples;
+ * WAVEFRONT keeps SoA ray queues in HBM and compacts them after every bounce. */
+typedef enum rrt_pipeline { RRT_PIPELINE_AUTO = 0, RRT_PIPELINE_FUSED = 1, RRT_PIPELINE_WAVEFRONT = 2 } rrt_pipeline;
+
+/* One primitive in the order the reference's linear scan visits it:
+ * objects in [[objects]] order (src/scene.rs:39), faces in file order inside a
+ * mesh (src/shapes/mesh.rs:32).  object_id = index into scene.objects,
+ * prim_id = face index inside the mesh, 0 for a non-mesh shape.
+ * Transforms are already applied (the `transform` of each file under src/shapes). */
+typedef struct rrt_prim {
+    uint32_t type; /* rrt_prim_type */
+    uint32_t object_id;
+    uint32_t prim_id;
+    uint32_t reserved;
+    double v[12];
+} rrt_prim;
+
+typedef struct rrt_material {
+    uint32_t type; /* rrt_material_type */
+    uint32_t reserved;
+    double rgb[3];
+    double param;
+} rrt_material;
+
+/* State of PerspectiveCamera (src/camera.rs:13-18). */
+typedef struct rrt_camera {
+    double origin[3];
+    double lower_left_corner[3];
+    double horizontal[3];
+    double vertical[3];
+} rrt_camera;
+
+typedef struct rrt_scene_desc {
+    rrt_camera camera;
+    uint32_t n_prims;
+    uint32_t n_objects;
+    const rrt_prim* prims;          /* n_prims, scan order */
+    const rrt_material* materials;  /* n_objects, one per object (src/object.rs:8-11) */
+} rrt_scene_desc;
+
+/* [tracer] + [image] + [sampler] of a render config (src/renderer.rs:12-25,
+ * src/tracers/mcpt.rs:14-18, src/sampler.rs:20-23,73-78) plus what a device
+ * backend needs and the reference has no notion of: a seed, a sample-index
+ * range (for sharding samples over GPUs), precision and kernel choices. */
+typedef struct rrt_render_desc {
+    uint32_t width, height;
+    uint32_t sampler_type;     /* rrt_sampler_type */
+    uint32_t spp;              /* samples_per_pixel as configured */
+    uint32_t x_strata, y_strata; /* stratified only; x*y must equal spp (src/sampler.rs:87-91) */
+    uint32_t min_depth, max_depth;
+    uint64_t sample_begin;     /* per-pixel sample indices [begin, end) traced by this call */
+    uint64_t sample_end;
+    uint64_t seed;
+    uint32_t precision;        /* rrt_precision */
+    uint32_t accel;            /* rrt_accel */
+    uint32_t pipeline;         /* rrt_pipeline */
+    uint32_t reserved;
+} rrt_render_desc;
+
+/* [post_processing] (src/renderer.rs:27-32). tone_mapping: 0 none, 1 reinhard. */
+typedef struct rrt_post_desc {
+    uint32_t tone_mapping;
+    uint32_t gamma_correction;
+    uint32_t has_white_balance;
+    uint32_t reserved;
+    double white_balance[3];
+} rrt_post_desc;
+
+typedef struct rrt_stats {
+    uint64_t samples;        /* camera samples traced */
+    uint64_t rays;           /* closest-hit queries = calls of Scene::intersect (src/tracers/utils.rs:36) */
+    uint64_t prim_tests;     /* primitive tests executed */
+    uint64_t node_tests;     /* LBVH node (AABB pair) visits */
+    uint64_t bounces[5];     /* scatter evaluations per rrt_material_type */
+    uint64_t nonfinite;      /* samples whose radiance was NaN/Inf (src/tracers/utils.rs:78-85 only warns) */
+    double kernel_ms;        /* device time of the tracing kernels (HIP events) */
+    double reserved;
+} rrt_stats;
+
+typedef struct rrt_scene rrt_scene;
+typedef struct rrt_backend rrt_backend;
+
+/* Thread-local text of the last error on this thread ("" if none). */
+const char* rrt_last_error(void);
+
+/* PerspectiveCamera::new (src/camera.rs:21-34): basis and image-plane vectors
+ * from look_from / look_at / vup / vertical fov in degrees / aspect. */
+int rrt_camera_perspective(const double look_from[3], const double look_at[3], const double vup[3],
+                           double vfov_deg, double aspect, rrt_camera* out);
+
+/* Scene::from_config minus the TOML parsing (src/scene.rs:20-33): validates
+ * and copies the description; the caller keeps ownership of `desc`. */
+int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out);
+void rrt_scene_destroy(rrt_scene* scene);
+
+/* Binds a backend to one GPU.  name must be "hip"; there is no CPU fallback.
+ * Takes the place of the rayon pool set-up in render (src/renderer.rs:74-78). */
+int rrt_backend_create(const char* name, int device_id, rrt_backend** out);
+void rrt_backend_destroy(rrt_backend* backend);
+/* Kernels and copies of later calls go to this hipStream_t (NULL = default). */
+int rrt_backend_set_stream(rrt_backend* backend, void* hip_stream);
+
+/* Scene::intersect (src/scene.rs:35-47) for n arbitrary rays.  origins/dirs are
+ * 3n host doubles; results are host arrays of n.  A miss gives ids -1 and
+ * t = +inf.  Directions must be unit length, as everywhere in the reference. */
+int rrt_intersect(rrt_backend* backend, const rrt_scene* scene, uint32_t precision, uint32_t accel,
+                  size_t n, const double* origins, const double* dirs,
+                  int32_t* object_id, int32_t* prim_id, double* t);
+
+/* Camera::create_ray (src/camera.rs:38-45) followed by Scene::intersect, for n
+ * image-plane coordinates (u, v) in [0,1]^2.  Host arrays. */
+int rrt_trace_primary(rrt_backend* backend, const rrt_scene* scene, uint32_t precision, uint32_t accel,
+                      size_t n, const double* u, const double* v,
+                      int32_t* object_id, int32_t* prim_id, double* t);
+
+/* The pixel/sample loop of render (src/renderer.rs:101-128) with
+ * MonteCarloPathTracer::trace (src/tracers/mcpt.rs:20-43) inside, for sample
+ * indices [sample_begin, sample_end) of every pixel.  ADDS the radiance of the
+ * traced samples to rgb_sum (width*height*3 floats, row-major, RGB), which the
+ * caller owns and zeroes; stats may be NULL. */
+int rrt_render_accumulate(rrt_backend* backend, const rrt_scene* scene, const rrt_render_desc* desc,
+                          float* rgb_sum_dev_or_host, rrt_stats* stats);
+
+/* color /= spp; post_process; quantise (src/renderer.rs:39-71,128-136):
+ * reinhard -> gamma 1/2.2 -> white balance -> min(c*255,255) truncated to u8
+ * (NaN becomes 255, negatives 0, as Rust's f64::min and `as u8` do). */
+int rrt_postprocess(rrt_backend* backend, const float* rgb_sum_dev_or_host, uint64_t spp_divisor,
+                    const rrt_post_desc* post, uint32_t width, uint32_t height,
+                    uint8_t* rgb8_dev_or_host);
+
+/* render (src/renderer.rs:73-150) in one call: zeroed accumulator, all samples
+ * of desc (RandomSampler traces spp+1 samples and still divides by spp,
+ * src/sampler.rs:48-55), post-process into rgb8 (host, width*height*3). */
+int rrt_render(rrt_backend* backend, const rrt_scene* scene, const rrt_render_desc* desc,
+               const rrt_post_desc* post, uint8_t* rgb8_host, rrt_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_H */
