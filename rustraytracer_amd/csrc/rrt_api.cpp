@@ -1,0 +1,602 @@
+// C ABI of the HIP backend (include/rrt.h): argument checking, host-side scene
+// preparation, device memory, kernel launches.  There is no CPU compute path in
+// this library: every entry point that traces rays runs kernels on a gfx950
+// device or fails with an error code.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rrt.h"
+#include "rrt_launch.hpp"
+#include "rrt_types.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(RRT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------ f64 vector helpers
+struct D3 {
+    double x, y, z;
+};
+D3 d3(const double* p) { return D3{p[0], p[1], p[2]}; }
+D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+D3 operator+(D3 a, D3 b) { return D3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+D3 operator*(D3 a, double s) { return D3{a.x * s, a.y * s, a.z * s}; }
+double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+D3 cross(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+D3 normalize(D3 a) { return a * (1.0 / std::sqrt(dot(a, a))); }  // cgmath: v * (1 / |v|)
+
+// ------------------------------------------------------------------ scene preparation
+// Plane-form records (see rrt_types.hpp / rrt_device.hpp) in f64.
+void prepare_prim(const rrt_prim& p, rrt::PrimRec<double>& rec, rrt::ShadeRec<double>& sh) {
+    std::memset(&rec, 0, sizeof(rec));
+    std::memset(&sh, 0, sizeof(sh));
+    rec.type = (int32_t)p.type;
+    sh.type = (int32_t)p.type;
+    sh.object_id = (int32_t)p.object_id;
+    sh.prim_id = (int32_t)p.prim_id;
+    const double* v = p.v;
+    if (p.type == RRT_PRIM_SPHERE) {
+        rec.f[0] = v[0]; rec.f[1] = v[1]; rec.f[2] = v[2];
+        rec.f[3] = v[3];
+        rec.f[4] = v[3] * v[3];
+        sh.nx = v[0]; sh.ny = v[1]; sh.nz = v[2]; sh.w = v[3];
+        return;
+    }
+    if (p.type == RRT_PRIM_PLANE) {
+        D3 point = d3(v), n = d3(v + 3);
+        rec.f[0] = n.x; rec.f[1] = n.y; rec.f[2] = n.z;
+        rec.f[3] = dot(n, point);
+        sh.nx = n.x; sh.ny = n.y; sh.nz = n.z;
+        return;
+    }
+    const bool quad = p.type == RRT_PRIM_QUAD;
+    D3 v0 = d3(v), v1 = d3(v + 3), v2 = d3(v + 6);
+    D3 vl = quad ? d3(v + 9) : v2;  // the corner that spans the second edge from v0
+    D3 e01 = v1 - v0, e03 = vl - v0;
+    D3 n = cross(e01, e03);
+    auto dual = [](D3 ea, D3 eb, D3 nn, D3 corner, double* out4) {
+        // coefficient of (P - corner) on ea in the basis (ea, eb) of the plane with normal nn
+        D3 k = cross(eb, nn);
+        double s = 1.0 / dot(ea, k);
+        out4[0] = k.x * s; out4[1] = k.y * s; out4[2] = k.z * s;
+        out4[3] = -(out4[0] * corner.x + out4[1] * corner.y + out4[2] * corner.z);
+    };
+    rec.f[0] = n.x; rec.f[1] = n.y; rec.f[2] = n.z;
+    rec.f[3] = dot(n, v0);
+    dual(e01, e03, n, v0, &rec.f[4]);
+    dual(e03, e01, n, v0, &rec.f[8]);
+    if (quad) {
+        D3 v3 = vl;
+        D3 e23 = v3 - v2, e21 = v1 - v2;
+        D3 n2 = cross(e23, e21);
+        dual(e23, e21, n2, v2, &rec.f[12]);
+        dual(e21, e23, n2, v2, &rec.f[16]);
+        rec.f[20] = n2.x; rec.f[21] = n2.y; rec.f[22] = n2.z;
+    }
+    // the normal the reference reports for a hit: normalize((v1-v0) x (v2-v0))
+    // (src/shapes/triangle.rs:78-80, quadrilateral.rs:180-182, mesh.rs:49-51,70-72)
+    D3 sn = normalize(cross(v1 - v0, v2 - v0));
+    sh.nx = sn.x; sh.ny = sn.y; sh.nz = sn.z;
+}
+
+void prepare_material(const rrt_material& m, rrt::MatRec<double>& out) {
+    std::memset(&out, 0, sizeof(out));
+    out.type = (int32_t)m.type;
+    out.r = m.rgb[0]; out.g = m.rgb[1]; out.b = m.rgb[2];
+    out.param = m.param;
+    double mag = std::sqrt(m.rgb[0] * m.rgb[0] + m.rgb[1] * m.rgb[1] + m.rgb[2] * m.rgb[2]);
+    out.emitter = (m.type == RRT_MAT_EMISSIVE && mag > 1e-6) ? 1 : 0;
+    if (m.type != RRT_MAT_EMISSIVE && m.type != RRT_MAT_LAMBERTIAN && m.type != RRT_MAT_PHONG) {
+        out.r = out.g = out.b = 0.0;
+    }
+}
+
+template <typename R>
+rrt::PrimRec<R> narrow(const rrt::PrimRec<double>& a) {
+    rrt::PrimRec<R> o;
+    for (int i = 0; i < 23; ++i) o.f[i] = (R)a.f[i];
+    o.type = a.type;
+    return o;
+}
+template <typename R>
+rrt::ShadeRec<R> narrow(const rrt::ShadeRec<double>& a) {
+    rrt::ShadeRec<R> o;
+    o.nx = (R)a.nx; o.ny = (R)a.ny; o.nz = (R)a.nz; o.w = (R)a.w;
+    o.object_id = a.object_id; o.prim_id = a.prim_id; o.type = a.type; o.pad = 0;
+    return o;
+}
+template <typename R>
+rrt::MatRec<R> narrow(const rrt::MatRec<double>& a) {
+    rrt::MatRec<R> o;
+    o.r = (R)a.r; o.g = (R)a.g; o.b = (R)a.b; o.param = (R)a.param;
+    o.type = a.type; o.emitter = a.emitter; o.pad[0] = o.pad[1] = 0;
+    return o;
+}
+
+struct DeviceScene {
+    int device = -1;
+    std::vector<void*> allocs;
+    rrt::SceneView<float> v32{};
+    rrt::SceneView<double> v64{};
+    bool has_bvh = false;
+    ~DeviceScene() {
+        if (device >= 0) {
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            (void)hipSetDevice(device);
+            for (void* p : allocs) (void)hipFree(p);
+            (void)hipSetDevice(cur);
+        }
+    }
+};
+
+}  // namespace
+
+struct rrt_scene {
+    rrt_camera camera;
+    std::vector<rrt_prim> prims;
+    std::vector<rrt_material> materials;
+    std::map<int, DeviceScene*> dev;
+};
+
+struct rrt_backend {
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long* d_counters = nullptr;  // COUNTER_COUNT + 1 (the last one is the work counter)
+};
+
+namespace {
+
+template <typename T>
+int upload(DeviceScene* ds, const std::vector<T>& host, const T** out, hipStream_t stream) {
+    *out = nullptr;
+    if (host.empty()) return RRT_OK;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, host.size() * sizeof(T)));
+    ds->allocs.push_back(p);
+    HIP_TRY(hipMemcpyAsync(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, stream));
+    *out = (const T*)p;
+    return RRT_OK;
+}
+
+template <typename R>
+int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view,
+              const std::vector<rrt::PrimRec<double>>& prims, const std::vector<rrt::ShadeRec<double>>& shade,
+              const std::vector<rrt::MatRec<double>>& mats, hipStream_t stream) {
+    std::vector<rrt::PrimRec<R>> p(prims.size());
+    std::vector<rrt::ShadeRec<R>> s(shade.size());
+    std::vector<rrt::MatRec<R>> m(mats.size());
+    for (size_t i = 0; i < prims.size(); ++i) p[i] = narrow<R>(prims[i]);
+    for (size_t i = 0; i < shade.size(); ++i) s[i] = narrow<R>(shade[i]);
+    for (size_t i = 0; i < mats.size(); ++i) m[i] = narrow<R>(mats[i]);
+    std::memset(&view, 0, sizeof(view));
+    for (int k = 0; k < 3; ++k) {
+        view.cam_o[k] = (R)sc->camera.origin[k];
+        view.cam_ll[k] = (R)(sc->camera.lower_left_corner[k] - sc->camera.origin[k]);
+        view.cam_h[k] = (R)sc->camera.horizontal[k];
+        view.cam_v[k] = (R)sc->camera.vertical[k];
+    }
+    int rc;
+    if ((rc = upload(ds, p, &view.prims, stream)) != RRT_OK) return rc;
+    if ((rc = upload(ds, s, &view.shade, stream)) != RRT_OK) return rc;
+    if ((rc = upload(ds, m, &view.mats, stream)) != RRT_OK) return rc;
+    view.n_prims = (int32_t)prims.size();
+    view.n_objects = (int32_t)mats.size();
+    HIP_TRY(hipStreamSynchronize(stream));  // the staging vectors die here
+    return RRT_OK;
+}
+
+// Device copy of a scene for the backend's GPU, built on first use.
+int device_scene(rrt_backend* be, const rrt_scene* sc_const, DeviceScene** out) {
+    rrt_scene* sc = const_cast<rrt_scene*>(sc_const);
+    auto it = sc->dev.find(be->device);
+    if (it != sc->dev.end()) {
+        *out = it->second;
+        return RRT_OK;
+    }
+    DeviceScene* ds = new (std::nothrow) DeviceScene();
+    if (!ds) return fail(RRT_ERR_NOMEM, "out of host memory");
+    ds->device = be->device;
+    std::vector<rrt::PrimRec<double>> prims(sc->prims.size());
+    std::vector<rrt::ShadeRec<double>> shade(sc->prims.size());
+    std::vector<rrt::MatRec<double>> mats(sc->materials.size());
+    for (size_t i = 0; i < sc->prims.size(); ++i) prepare_prim(sc->prims[i], prims[i], shade[i]);
+    for (size_t i = 0; i < sc->materials.size(); ++i) prepare_material(sc->materials[i], mats[i]);
+    int rc = fill_view<float>(ds, sc, ds->v32, prims, shade, mats, be->stream);
+    if (rc == RRT_OK) rc = fill_view<double>(ds, sc, ds->v64, prims, shade, mats, be->stream);
+    if (rc != RRT_OK) {
+        delete ds;
+        return rc;
+    }
+    sc->dev[be->device] = ds;
+    *out = ds;
+    return RRT_OK;
+}
+
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // plain host memory is reported as an error; clear it
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+int check_backend(rrt_backend* be) {
+    if (!be) return fail(RRT_ERR_INVALID, "backend is NULL");
+    HIP_TRY(hipSetDevice(be->device));
+    return RRT_OK;
+}
+
+int closest_hit_call(rrt_backend* be, const rrt_scene* scene, uint32_t precision, uint32_t accel, bool primary,
+                     size_t n, const double* a, const double* b, int32_t* object_id, int32_t* prim_id, double* t) {
+    int rc = check_backend(be);
+    if (rc != RRT_OK) return rc;
+    if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
+    if (precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", precision);
+    if (accel > RRT_ACCEL_LBVH) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
+    if (n == 0) return RRT_OK;
+    if (!a || !b || !object_id || !prim_id || !t) return fail(RRT_ERR_INVALID, "NULL array argument");
+    if (scene->prims.empty()) {
+        for (size_t i = 0; i < n; ++i) {
+            object_id[i] = -1;
+            prim_id[i] = -1;
+            t[i] = INFINITY;
+        }
+        return RRT_OK;
+    }
+    if (accel == RRT_ACCEL_LBVH) return fail(RRT_ERR_UNSUPPORTED, "LBVH traversal is not built into this library yet");
+    DeviceScene* ds = nullptr;
+    if ((rc = device_scene(be, scene, &ds)) != RRT_OK) return rc;
+    const size_t per = primary ? 1 : 3;
+    DevBuf da, db, doid, dpid, dt;
+    HIP_TRY(da.alloc(n * per * sizeof(double)));
+    HIP_TRY(db.alloc(n * per * sizeof(double)));
+    HIP_TRY(doid.alloc(n * sizeof(int32_t)));
+    HIP_TRY(dpid.alloc(n * sizeof(int32_t)));
+    HIP_TRY(dt.alloc(n * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(da.p, a, n * per * sizeof(double), hipMemcpyHostToDevice, be->stream));
+    HIP_TRY(hipMemcpyAsync(db.p, b, n * per * sizeof(double), hipMemcpyHostToDevice, be->stream));
+    if (precision == RRT_PRECISION_F64)
+        HIP_TRY(rrt::launch_intersect(ds->v64, primary, n, (const double*)da.p, (const double*)db.p,
+                                      (int32_t*)doid.p, (int32_t*)dpid.p, (double*)dt.p, be->stream));
+    else
+        HIP_TRY(rrt::launch_intersect(ds->v32, primary, n, (const double*)da.p, (const double*)db.p,
+                                      (int32_t*)doid.p, (int32_t*)dpid.p, (double*)dt.p, be->stream));
+    HIP_TRY(hipMemcpyAsync(object_id, doid.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipMemcpyAsync(prim_id, dpid.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipMemcpyAsync(t, dt.p, n * sizeof(double), hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipStreamSynchronize(be->stream));
+    return RRT_OK;
+}
+
+uint32_t next_pow2_mask(uint32_t l) {
+    uint32_t w = l - 1;
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    return w;
+}
+
+int validate_render_desc(const rrt_render_desc* d) {
+    if (!d) return fail(RRT_ERR_INVALID, "render desc is NULL");
+    if (d->width == 0 || d->height == 0) return fail(RRT_ERR_INVALID, "image size %ux%u", d->width, d->height);
+    if ((uint64_t)d->width * d->height > (1ull << 28)) return fail(RRT_ERR_INVALID, "image too large");
+    if (d->sampler_type > RRT_SAMPLER_STRATIFIED) return fail(RRT_ERR_INVALID, "unknown sampler type %u", d->sampler_type);
+    if (d->spp == 0) return fail(RRT_ERR_INVALID, "samples_per_pixel must be positive");
+    if (d->sampler_type == RRT_SAMPLER_STRATIFIED) {
+        // assert_eq!(x_strata * y_strata, samples_per_pixel), src/sampler.rs:87-91
+        if ((uint64_t)d->x_strata * d->y_strata != d->spp)
+            return fail(RRT_ERR_INVALID, "x_strata * y_strata != samples_per_pixel");
+        if (d->sample_end > d->spp)
+            return fail(RRT_ERR_INVALID, "stratified sample index range ends at %llu > spp %u",
+                        (unsigned long long)d->sample_end, d->spp);
+    }
+    if (d->sample_end <= d->sample_begin) return fail(RRT_ERR_INVALID, "empty sample range");
+    if (d->sample_end > 0x7fffffffull) return fail(RRT_ERR_INVALID, "sample index beyond 2^31");
+    if (d->precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", d->precision);
+    if (d->accel > RRT_ACCEL_LBVH) return fail(RRT_ERR_INVALID, "unknown accel %u", d->accel);
+    if (d->pipeline > RRT_PIPELINE_WAVEFRONT) return fail(RRT_ERR_INVALID, "unknown pipeline %u", d->pipeline);
+    return RRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rrt_last_error(void) { return g_last_error.c_str(); }
+
+int rrt_camera_perspective(const double look_from[3], const double look_at[3], const double vup[3],
+                           double vfov_deg, double aspect, rrt_camera* out) {
+    if (!look_from || !look_at || !vup || !out) return fail(RRT_ERR_INVALID, "NULL argument");
+    const double PI = 3.14159265358979323846264338327950288;
+    double theta = vfov_deg * PI / 180.0;
+    double half_height = std::tan(theta / 2.0);
+    double half_width = aspect * half_height;
+    D3 from = d3(look_from);
+    D3 w = normalize(from - d3(look_at));
+    D3 u = normalize(cross(d3(vup), w));
+    D3 v = cross(w, u);
+    D3 ll = from - u * half_width - v * half_height - w;
+    D3 h = u * (2.0 * half_width), ve = v * (2.0 * half_height);
+    out->origin[0] = from.x; out->origin[1] = from.y; out->origin[2] = from.z;
+    out->lower_left_corner[0] = ll.x; out->lower_left_corner[1] = ll.y; out->lower_left_corner[2] = ll.z;
+    out->horizontal[0] = h.x; out->horizontal[1] = h.y; out->horizontal[2] = h.z;
+    out->vertical[0] = ve.x; out->vertical[1] = ve.y; out->vertical[2] = ve.z;
+    return RRT_OK;
+}
+
+int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
+    if (!desc || !out) return fail(RRT_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (desc->n_prims && !desc->prims) return fail(RRT_ERR_INVALID, "prims is NULL");
+    if (desc->n_objects && !desc->materials) return fail(RRT_ERR_INVALID, "materials is NULL");
+    if (desc->n_prims > 0x7fffffffu) return fail(RRT_ERR_INVALID, "too many primitives");
+    for (uint32_t i = 0; i < desc->n_prims; ++i) {
+        const rrt_prim& p = desc->prims[i];
+        if (p.type > RRT_PRIM_QUAD) return fail(RRT_ERR_INVALID, "prim %u: unknown type %u", i, p.type);
+        if (p.object_id >= desc->n_objects)
+            return fail(RRT_ERR_INVALID, "prim %u: object_id %u out of range", i, p.object_id);
+        static const int used[4] = {4, 6, 9, 12};
+        for (int k = 0; k < used[p.type]; ++k)
+            if (!std::isfinite(p.v[k])) return fail(RRT_ERR_INVALID, "prim %u: non-finite coordinate", i);
+    }
+    for (uint32_t i = 0; i < desc->n_objects; ++i)
+        if (desc->materials[i].type > RRT_MAT_DIELECTRIC)
+            return fail(RRT_ERR_INVALID, "object %u: unknown material type %u", i, desc->materials[i].type);
+    rrt_scene* sc = new (std::nothrow) rrt_scene();
+    if (!sc) return fail(RRT_ERR_NOMEM, "out of host memory");
+    sc->camera = desc->camera;
+    sc->prims.assign(desc->prims, desc->prims + desc->n_prims);
+    sc->materials.assign(desc->materials, desc->materials + desc->n_objects);
+    *out = sc;
+    return RRT_OK;
+}
+
+void rrt_scene_destroy(rrt_scene* scene) {
+    if (!scene) return;
+    for (auto& kv : scene->dev) delete kv.second;
+    delete scene;
+}
+
+int rrt_backend_create(const char* name, int device_id, rrt_backend** out) {
+    if (!name || !out) return fail(RRT_ERR_INVALID, "NULL argument");
+    *out = nullptr;
+    if (std::strcmp(name, "hip") != 0)
+        return fail(RRT_ERR_UNSUPPORTED, "unknown backend \"%s\" (this library only has \"hip\")", name);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(RRT_ERR_NO_DEVICE, "no HIP device is visible");
+    }
+    if (device_id < 0 || device_id >= count)
+        return fail(RRT_ERR_NO_DEVICE, "device %d out of range (%d visible)", device_id, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RRT_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device_id,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device_id));
+    rrt_backend* be = new (std::nothrow) rrt_backend();
+    if (!be) return fail(RRT_ERR_NOMEM, "out of host memory");
+    be->device = device_id;
+    be->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipEventCreate(&be->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&be->ev1);
+    if (e == hipSuccess) e = hipMalloc((void**)&be->d_counters, sizeof(unsigned long long) * (rrt::COUNTER_COUNT + 1));
+    if (e != hipSuccess) {
+        rrt_backend_destroy(be);
+        return fail(RRT_ERR_HIP, "backend set-up failed: %s", hipGetErrorString(e));
+    }
+    *out = be;
+    return RRT_OK;
+}
+
+void rrt_backend_destroy(rrt_backend* be) {
+    if (!be) return;
+    (void)hipSetDevice(be->device);
+    if (be->ev0) (void)hipEventDestroy(be->ev0);
+    if (be->ev1) (void)hipEventDestroy(be->ev1);
+    if (be->d_counters) (void)hipFree(be->d_counters);
+    delete be;
+}
+
+int rrt_backend_set_stream(rrt_backend* be, void* hip_stream) {
+    if (!be) return fail(RRT_ERR_INVALID, "backend is NULL");
+    be->stream = (hipStream_t)hip_stream;
+    return RRT_OK;
+}
+
+int rrt_intersect(rrt_backend* be, const rrt_scene* scene, uint32_t precision, uint32_t accel, size_t n,
+                  const double* origins, const double* dirs, int32_t* object_id, int32_t* prim_id, double* t) {
+    return closest_hit_call(be, scene, precision, accel, false, n, origins, dirs, object_id, prim_id, t);
+}
+
+int rrt_trace_primary(rrt_backend* be, const rrt_scene* scene, uint32_t precision, uint32_t accel, size_t n,
+                      const double* u, const double* v, int32_t* object_id, int32_t* prim_id, double* t) {
+    return closest_hit_call(be, scene, precision, accel, true, n, u, v, object_id, prim_id, t);
+}
+
+int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_render_desc* desc,
+                          float* rgb_sum, rrt_stats* stats) {
+    int rc = check_backend(be);
+    if (rc != RRT_OK) return rc;
+    if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
+    if (!rgb_sum) return fail(RRT_ERR_INVALID, "rgb_sum is NULL");
+    if ((rc = validate_render_desc(desc)) != RRT_OK) return rc;
+    if (desc->pipeline == RRT_PIPELINE_WAVEFRONT)
+        return fail(RRT_ERR_UNSUPPORTED, "the wavefront pipeline is not built into this library yet");
+    if (desc->accel == RRT_ACCEL_LBVH)
+        return fail(RRT_ERR_UNSUPPORTED, "LBVH traversal is not built into this library yet");
+    DeviceScene* ds = nullptr;
+    if ((rc = device_scene(be, scene, &ds)) != RRT_OK) return rc;
+
+    const size_t n_pixels = (size_t)desc->width * desc->height;
+    const bool on_device = is_device_pointer(rgb_sum);
+    DevBuf staging;
+    float* d_accum = rgb_sum;
+    if (!on_device) {
+        HIP_TRY(staging.alloc(n_pixels * 3 * sizeof(float)));
+        d_accum = (float*)staging.p;
+        HIP_TRY(hipMemsetAsync(d_accum, 0, n_pixels * 3 * sizeof(float), be->stream));
+    }
+
+    rrt::RenderParams rp;
+    std::memset(&rp, 0, sizeof(rp));
+    rp.width = desc->width;
+    rp.height = desc->height;
+    rp.sampler_type = desc->sampler_type;
+    rp.spp = desc->spp;
+    rp.x_strata = desc->x_strata ? desc->x_strata : 1;
+    rp.y_strata = desc->y_strata ? desc->y_strata : 1;
+    rp.x_shift = 0xffffffffu;
+    if ((rp.x_strata & (rp.x_strata - 1)) == 0) {
+        rp.x_shift = 0;
+        while ((1u << rp.x_shift) < rp.x_strata) rp.x_shift++;
+    }
+    rp.perm_mask = next_pow2_mask(desc->spp);
+    rp.min_depth = desc->min_depth;
+    rp.max_depth = desc->max_depth;
+    rp.sample_begin = (uint32_t)desc->sample_begin;
+    rp.n_samples = (uint32_t)(desc->sample_end - desc->sample_begin);
+    // samples per work item: enough items to balance the tail, few enough to keep
+    // the per-item atomics and the 32-bit item index negligible / valid
+    uint32_t chunk = rp.n_samples < 128 ? rp.n_samples : 128;
+    while ((uint64_t)((rp.n_samples + chunk - 1) / chunk) * n_pixels >= (1ull << 31)) chunk *= 2;
+    rp.chunk = chunk;
+    rp.n_chunks = (rp.n_samples + chunk - 1) / chunk;
+    rp.n_items = (uint64_t)rp.n_chunks * n_pixels;
+    rp.seed_lo = (uint32_t)desc->seed;
+    rp.seed_hi = (uint32_t)(desc->seed >> 32);
+    rp.accum = d_accum;
+    rp.counters = be->d_counters;
+    rp.work_counter = be->d_counters + rrt::COUNTER_COUNT;
+
+    HIP_TRY(hipMemsetAsync(be->d_counters, 0, sizeof(unsigned long long) * (rrt::COUNTER_COUNT + 1), be->stream));
+    // 8 blocks of 4 waves per CU is the most a CU holds; fewer lanes than items are never needed
+    uint64_t max_blocks = (uint64_t)be->n_cu * 8;
+    uint64_t want = (rp.n_items + 255) / 256;
+    int n_blocks = (int)(want < max_blocks ? want : max_blocks);
+    if (n_blocks < 1) n_blocks = 1;
+
+    HIP_TRY(hipEventRecord(be->ev0, be->stream));
+    if (desc->max_depth > 0) {
+        if (desc->precision == RRT_PRECISION_F64)
+            HIP_TRY(rrt::launch_render_fused(ds->v64, rp, n_blocks, be->stream));
+        else
+            HIP_TRY(rrt::launch_render_fused(ds->v32, rp, n_blocks, be->stream));
+    }
+    HIP_TRY(hipEventRecord(be->ev1, be->stream));
+
+    unsigned long long counters[rrt::COUNTER_COUNT + 1];
+    HIP_TRY(hipMemcpyAsync(counters, be->d_counters, sizeof(counters), hipMemcpyDeviceToHost, be->stream));
+    std::vector<float> host_tmp;
+    if (!on_device) {
+        host_tmp.resize(n_pixels * 3);
+        HIP_TRY(hipMemcpyAsync(host_tmp.data(), d_accum, n_pixels * 3 * sizeof(float), hipMemcpyDeviceToHost,
+                               be->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(be->stream));
+    if (!on_device)
+        for (size_t i = 0; i < n_pixels * 3; ++i) rgb_sum[i] += host_tmp[i];
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, be->ev0, be->ev1));
+        stats->kernel_ms = ms;
+        stats->samples = desc->max_depth > 0 ? counters[rrt::COUNTER_SAMPLES] : (uint64_t)rp.n_samples * n_pixels;
+        stats->rays = counters[rrt::COUNTER_RAYS];
+        stats->prim_tests = counters[rrt::COUNTER_PRIM_TESTS];
+        stats->node_tests = counters[rrt::COUNTER_NODE_TESTS];
+        for (int k = 0; k < 5; ++k) stats->bounces[k] = counters[rrt::COUNTER_BOUNCE0 + k];
+        stats->nonfinite = counters[rrt::COUNTER_NONFINITE];
+    }
+    return RRT_OK;
+}
+
+int rrt_postprocess(rrt_backend* be, const float* rgb_sum, uint64_t spp_divisor, const rrt_post_desc* post,
+                    uint32_t width, uint32_t height, uint8_t* rgb8) {
+    int rc = check_backend(be);
+    if (rc != RRT_OK) return rc;
+    if (!rgb_sum || !post || !rgb8) return fail(RRT_ERR_INVALID, "NULL argument");
+    if (spp_divisor == 0) return fail(RRT_ERR_INVALID, "spp divisor is zero");
+    if (post->tone_mapping > 1) return fail(RRT_ERR_INVALID, "unknown tone mapping %u", post->tone_mapping);
+    const size_t n = (size_t)width * height * 3;
+    if (n == 0) return RRT_OK;
+    DevBuf in_stage, out_stage;
+    const float* d_in = rgb_sum;
+    uint8_t* d_out = rgb8;
+    const bool in_dev = is_device_pointer(rgb_sum), out_dev = is_device_pointer(rgb8);
+    if (!in_dev) {
+        HIP_TRY(in_stage.alloc(n * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(in_stage.p, rgb_sum, n * sizeof(float), hipMemcpyHostToDevice, be->stream));
+        d_in = (const float*)in_stage.p;
+    }
+    if (!out_dev) {
+        HIP_TRY(out_stage.alloc(n));
+        d_out = (uint8_t*)out_stage.p;
+    }
+    rrt::PostParams pp;
+    pp.tone_mapping = (int32_t)post->tone_mapping;
+    pp.gamma = post->gamma_correction ? 1 : 0;
+    pp.has_wb = post->has_white_balance ? 1 : 0;
+    pp.pad = 0;
+    for (int k = 0; k < 3; ++k) pp.wb[k] = post->white_balance[k];
+    HIP_TRY(rrt::launch_postprocess(d_in, 1.0 / (double)spp_divisor, pp, n, d_out, be->stream));
+    if (!out_dev) HIP_TRY(hipMemcpyAsync(rgb8, d_out, n, hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipStreamSynchronize(be->stream));
+    return RRT_OK;
+}
+
+int rrt_render(rrt_backend* be, const rrt_scene* scene, const rrt_render_desc* desc, const rrt_post_desc* post,
+               uint8_t* rgb8_host, rrt_stats* stats) {
+    int rc = check_backend(be);
+    if (rc != RRT_OK) return rc;
+    if (!desc || !post || !rgb8_host) return fail(RRT_ERR_INVALID, "NULL argument");
+    rrt_render_desc d = *desc;
+    // all samples of the pixel loop: Random starts spp + 1 samples (src/sampler.rs:48-55)
+    d.sample_begin = 0;
+    d.sample_end = (uint64_t)d.spp + (d.sampler_type == RRT_SAMPLER_RANDOM ? 1 : 0);
+    const size_t n = (size_t)d.width * d.height * 3;
+    DevBuf accum;
+    HIP_TRY(accum.alloc(n * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(accum.p, 0, n * sizeof(float), be->stream));
+    if ((rc = rrt_render_accumulate(be, scene, &d, (float*)accum.p, stats)) != RRT_OK) return rc;
+    return rrt_postprocess(be, (const float*)accum.p, d.spp, post, d.width, d.height, rgb8_host);
+}
+
+}  // extern "C"

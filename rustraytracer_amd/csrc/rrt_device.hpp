@@ -1,0 +1,314 @@
+// Device functions of the path tracer: arithmetic helpers, counter-based RNG,
+// the stateless stratified sampler, ray/primitive tests and closest-hit.
+//
+// Everything is templated on the arithmetic type R: float is the production
+// path (FP32 VALU), double exists so that hit decisions can be compared with
+// an f64 CPU implementation without f32 rounding in the way.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rrt_types.hpp"
+
+namespace rrt {
+
+#define RRT_DEV __device__ __forceinline__
+
+// Scene tables never change while a kernel runs.  Reading them through the
+// constant address space lets the compiler use scalar loads (s_load_*) whenever
+// the index is wave-uniform; through a plain global pointer it must assume the
+// kernel's own atomics could alias the table and falls back to vector loads.
+#define RRT_CONSTANT __attribute__((address_space(4)))
+template <typename T>
+RRT_DEV const T RRT_CONSTANT* as_constant(const T* p) {
+    return (const T RRT_CONSTANT*)p;
+}
+
+// ---------------------------------------------------------------- arithmetic
+template <typename R>
+struct Num;
+
+template <>
+struct Num<float> {
+    static RRT_DEV float tmin() { return 0.001f; }            // src/scene.rs:40
+    static RRT_DEV float tmax() { return 3.402823466e+38f; }  // largest finite value of R
+    static RRT_DEV float eps() { return 1e-6f; }
+    static RRT_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static RRT_DEV float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+    static RRT_DEV float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static RRT_DEV float abs(float x) { return __builtin_fabsf(x); }
+    // sin / cos of 2*pi*x, x in [0,1): v_sin_f32 / v_cos_f32 take revolutions
+    static RRT_DEV void sincos2pi(float x, float& s, float& c) {
+        s = __builtin_amdgcn_sinf(x);
+        c = __builtin_amdgcn_cosf(x);
+    }
+    // x^e for x in [0,1], e > 0
+    static RRT_DEV float pow(float x, float e) {
+        return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x));
+    }
+    static RRT_DEV float uniform(uint32_t bits) { return (float)(bits >> 8) * 5.9604644775390625e-8f; }
+    static RRT_DEV float inv_pi() { return 0.318309886183790671538f; }
+};
+
+template <>
+struct Num<double> {
+    static RRT_DEV double tmin() { return 0.001; }
+    static RRT_DEV double tmax() { return 1.7976931348623157e308; }  // f64::MAX, src/scene.rs:37
+    static RRT_DEV double eps() { return 1e-6; }
+    static RRT_DEV double rcp(double x) { return 1.0 / x; }
+    static RRT_DEV double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static RRT_DEV double sqrt(double x) { return ::sqrt(x); }
+    static RRT_DEV double abs(double x) { return ::fabs(x); }
+    static RRT_DEV void sincos2pi(double x, double& s, double& c) { ::sincospi(2.0 * x, &s, &c); }
+    static RRT_DEV double pow(double x, double e) { return ::pow(x, e); }
+    static RRT_DEV double uniform(uint32_t bits) { return (double)bits * 2.3283064365386962890625e-10; }
+    static RRT_DEV double inv_pi() { return 0.318309886183790671538; }
+};
+
+template <typename R>
+struct V3 {
+    R x, y, z;
+};
+template <typename R>
+RRT_DEV V3<R> mk(R x, R y, R z) {
+    V3<R> r{x, y, z};
+    return r;
+}
+template <typename R>
+RRT_DEV R dot(V3<R> a, V3<R> b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+template <typename R>
+RRT_DEV V3<R> cross(V3<R> a, V3<R> b) {
+    return mk<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <typename R>
+RRT_DEV V3<R> operator+(V3<R> a, V3<R> b) {
+    return mk<R>(a.x + b.x, a.y + b.y, a.z + b.z);
+}
+template <typename R>
+RRT_DEV V3<R> operator-(V3<R> a, V3<R> b) {
+    return mk<R>(a.x - b.x, a.y - b.y, a.z - b.z);
+}
+template <typename R>
+RRT_DEV V3<R> operator*(V3<R> a, R s) {
+    return mk<R>(a.x * s, a.y * s, a.z * s);
+}
+template <typename R>
+RRT_DEV V3<R> normalize(V3<R> a) {
+    return a * Num<R>::rsqrt(dot(a, a));
+}
+
+// ---------------------------------------------------------------- RNG
+// Counter-based: every number is a hash of (seed, pixel, sample, draw index);
+// there is no generator state to carry in a queue or to advance in order.
+RRT_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+RRT_DEV uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t pixel) {
+    return mix32(seed_lo ^ mix32(pixel * 0x9E3779B1U + (mix32(seed_hi) | 1U)));
+}
+RRT_DEV uint32_t sample_key(uint32_t pixkey, uint32_t sample) {
+    return mix32(pixkey + mix32(sample ^ 0x85EBCA6BU) * 0xC2B2AE35U);
+}
+
+// Kensler's hash-based permutation of {0..l-1} ("Correlated Multi-Jittered
+// Sampling", Pixar TM 13-01): a bijection for every key p, evaluated for one
+// index at a time, which replaces the reference's per-pixel shuffled tables
+// (src/sampler.rs:105-125).  w = next_pow2(l) - 1.
+RRT_DEV uint32_t permute(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
+    do {
+        i ^= p;
+        i *= 0xe170893dU;
+        i ^= p >> 16;
+        i ^= (i & w) >> 4;
+        i ^= p >> 8;
+        i *= 0x0929eb3fU;
+        i ^= p >> 23;
+        i ^= (i & w) >> 1;
+        i *= 1U | p >> 27;
+        i *= 0x6935fa69U;
+        i ^= (i & w) >> 11;
+        i *= 0x74dcb303U;
+        i ^= (i & w) >> 2;
+        i *= 0x9e501cc3U;
+        i ^= (i & w) >> 2;
+        i *= 0xc860a3dfU;
+        i &= w;
+        i ^= i >> 5;
+    } while (i >= l);
+    uint32_t r = i + p;
+    return (l & (l - 1)) == 0 ? (r & w) : (r % l);
+}
+
+// Sampler of one camera sample.  `dim` is the reference's current_dimension:
+// ONE counter shared by get_1d and get_2d (src/sampler.rs:135-151); the first
+// four dimensions are stratified over the pixel's samples, later draws are
+// plain uniforms.  The Random sampler is the same object with dim pinned at 4.
+struct Sampler {
+    uint32_t pixkey;  // hash(seed, pixel): keys the per-dimension permutations
+    uint32_t key;     // hash(pixkey, sample): keys the uniforms of this sample
+    uint32_t sample;  // sample index inside the pixel
+    uint32_t ctr;     // uniforms drawn so far
+    uint32_t dim;
+};
+
+RRT_DEV uint32_t next_bits(Sampler& s) { return mix32(s.key + (s.ctr++) * 0x9E3779B9U); }
+
+RRT_DEV void sampler_start(Sampler& s, const RenderParams& rp, uint32_t pixkey, uint32_t sample) {
+    s.pixkey = pixkey;
+    s.sample = sample;
+    s.key = sample_key(pixkey, sample);
+    s.ctr = 0;
+    s.dim = rp.sampler_type == 1 ? 0u : 4u;
+}
+
+// get_1d.  `needed` = false when the caller will not look at the value (the
+// Russian-roulette draw against probability 1, src/tracers/utils.rs:56-63):
+// the dimension is still consumed, as in the reference.
+template <typename R>
+RRT_DEV R get_1d(Sampler& s, const RenderParams& rp, bool needed) {
+    if (s.dim < 4u) {
+        uint32_t d = s.dim++;
+        if (!needed) return R(0);
+        uint32_t k = mix32(s.pixkey ^ ((2u * d + 1u) * 0x9E3779B9U));
+        uint32_t stratum = permute(s.sample, rp.spp, rp.perm_mask, k);
+        R j = Num<R>::uniform(next_bits(s));
+        return ((R)stratum + j) / (R)rp.spp;  // (i + xi) / spp, src/sampler.rs:108
+    }
+    if (!needed) return R(0);
+    return Num<R>::uniform(next_bits(s));
+}
+
+template <typename R>
+RRT_DEV void get_2d(Sampler& s, const RenderParams& rp, R& a, R& b) {
+    R j0 = Num<R>::uniform(next_bits(s));
+    R j1 = Num<R>::uniform(next_bits(s));
+    if (s.dim < 4u) {
+        uint32_t d = s.dim++;
+        uint32_t k = mix32(s.pixkey ^ ((2u * d + 2u) * 0x9E3779B9U));
+        uint32_t cell = permute(s.sample, rp.spp, rp.perm_mask, k);
+        uint32_t xc, yc;  // x_cell = i % x_strata, y_cell = i / x_strata, src/sampler.rs:115-116
+        if (rp.x_shift != 0xffffffffu) {
+            xc = cell & (rp.x_strata - 1u);
+            yc = cell >> rp.x_shift;
+        } else {
+            yc = cell / rp.x_strata;
+            xc = cell - yc * rp.x_strata;
+        }
+        a = ((R)xc + j0) / (R)rp.x_strata;
+        b = ((R)yc + j1) / (R)rp.y_strata;
+        return;
+    }
+    a = j0;
+    b = j1;
+}
+
+// ---------------------------------------------------------------- camera
+// Camera::create_ray (src/camera.rs:38-45); cam_ll already has the origin subtracted.
+template <typename R>
+RRT_DEV V3<R> camera_dir(const SceneView<R>& sv, R s, R t) {
+    V3<R> d = mk<R>(sv.cam_ll[0] + s * sv.cam_h[0] + t * sv.cam_v[0],
+                    sv.cam_ll[1] + s * sv.cam_h[1] + t * sv.cam_v[1],
+                    sv.cam_ll[2] + s * sv.cam_h[2] + t * sv.cam_v[2]);
+    return normalize(d);
+}
+
+// ---------------------------------------------------------------- primitive tests
+// One primitive against one ray for t in the interval the reference accepts
+// (closed [t_min, t_max] for sphere / plane / quad, open for triangles).
+// Returns true and t when the primitive replaces the current closest hit.
+//
+// Triangles and quads use the plane form of the reference's tests
+// (src/shapes/triangle.rs:22-61, src/shapes/quadrilateral.rs:56-117):
+//   det   = e01 . (d x e03) = -(n . d)            -> same |det| < 1e-6 reject
+//   ray_t = e03 . ((o-v0) x e01) / det = (n.v0 - n.o) / (n.d)
+//   alpha = (o-v0) . (d x e03) / det = coefficient of (P - v0) on e01
+//   beta  = d . ((o-v0) x e01) / det = coefficient of (P - v0) on e03
+// with P = o + t d.  The coefficients are affine in P, so they are two dot
+// products with vectors prepared on the host.  Same accept/reject conditions,
+// about half the arithmetic.  The second corner test of a quad is evaluated
+// at the same P (the reference intersects the second triangle's own plane,
+// which is the same plane for the planar quads its loader admits).
+template <typename R>
+RRT_DEV bool prim_test(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
+    const R RRT_CONSTANT* f = p->f;
+    const int type = p->type;  // wave-uniform in the linear scan
+    if (type >= PRIM_TRIANGLE) {
+        R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
+        R no = f[3] - (f[0] * o.x + f[1] * o.y + f[2] * o.z);
+        R t = no * Num<R>::rcp(nd);
+        bool ok = !(Num<R>::abs(nd) < Num<R>::eps());
+        if (type == PRIM_QUAD)
+            ok = ok && !(t < Num<R>::tmin()) && !(t > best_t);
+        else
+            ok = ok && (t > Num<R>::tmin()) && (t < best_t);
+        if (__any(ok)) {
+            V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+            R a = f[4] * P.x + f[5] * P.y + f[6] * P.z + f[7];
+            R b = f[8] * P.x + f[9] * P.y + f[10] * P.z + f[11];
+            ok = ok && !(a < R(0)) && !(b < R(0));
+            if (type == PRIM_QUAD) {
+                R a2 = f[12] * P.x + f[13] * P.y + f[14] * P.z + f[15];
+                R b2 = f[16] * P.x + f[17] * P.y + f[18] * P.z + f[19];
+                R nd2 = f[20] * d.x + f[21] * d.y + f[22] * d.z;
+                bool second = (a + b) > R(1);
+                bool ok2 = !(Num<R>::abs(nd2) < Num<R>::eps()) && !(a2 < R(0)) && !(b2 < R(0));
+                ok = ok && (!second || ok2);
+            } else {
+                ok = ok && !(a > R(1)) && !((a + b) > R(1));
+            }
+        }
+        t_out = t;
+        return ok;
+    }
+    if (type == PRIM_SPHERE) {  // src/shapes/sphere.rs:58-96
+        V3<R> l = mk<R>(f[0] - o.x, f[1] - o.y, f[2] - o.z);
+        R t_ca = dot(l, d);
+        R d2 = dot(l, l) - t_ca * t_ca;
+        R r2 = f[4];
+        bool ok = !(d2 < R(0)) && !(d2 > r2);
+        R t_hc = Num<R>::sqrt(r2 - d2);
+        R t0 = t_ca - t_hc;
+        R t1 = t_ca + t_hc;
+        if (t0 < Num<R>::tmin()) t0 = t1;
+        ok = ok && !(t0 < Num<R>::tmin()) && !(t0 > best_t);
+        t_out = t0;
+        return ok;
+    }
+    // plane, src/shapes/plane.rs:25-44
+    R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
+    R no = f[3] - (f[0] * o.x + f[1] * o.y + f[2] * o.z);
+    R t = no * Num<R>::rcp(nd);
+    t_out = t;
+    return !(Num<R>::abs(nd) < Num<R>::eps()) && !(t < Num<R>::tmin()) && !(t > best_t);
+}
+
+struct HitCounters {
+    uint32_t prim_tests;
+    uint32_t node_tests;
+};
+
+// Scene::intersect (src/scene.rs:35-47) as a scan over the primitive table in
+// the reference's order with a shrinking t_max.  The table index is uniform
+// across the wave, so records arrive through scalar loads.
+template <typename R>
+RRT_DEV void scan_linear(const SceneView<R>& sv, V3<R> o, V3<R> d, R& best_t, int& best_g,
+                         HitCounters& hc) {
+    const int n = sv.n_prims;
+    const PrimRec<R> RRT_CONSTANT* prims = as_constant(sv.prims);
+    for (int i = 0; i < n; ++i) {
+        R t;
+        if (prim_test(prims + i, o, d, best_t, t)) {
+            best_t = t;
+            best_g = i;
+        }
+    }
+}
+
+}  // namespace rrt

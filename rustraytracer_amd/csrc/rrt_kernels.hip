@@ -1,0 +1,241 @@
+// gfx950 kernels of the path tracer and their launch wrappers.
+//
+//   intersect_kernel   Scene::intersect for arbitrary rays (parity gate)
+//   primary_kernel     Camera::create_ray + Scene::intersect for (u, v) pairs
+//   render_fused       the pixel/sample loop of render() with the MCPT bounce
+//                      loop inside: one path per lane, kept in registers for
+//                      all of its bounces; a lane whose path ended starts the
+//                      next camera sample at once, so every closest-hit scan
+//                      runs with (almost) all 64 lanes live
+//   postprocess_kernel mean -> reinhard -> gamma -> white balance -> u8
+#include <hip/hip_runtime.h>
+
+#include "rrt_launch.hpp"
+#include "rrt_shade.hpp"
+
+namespace rrt {
+
+// Closest hit over the whole scene.  Returns the scan-order primitive index or -1.
+template <typename R, bool BVH>
+RRT_DEV int closest_hit(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t, HitCounters& hc) {
+    R best_t = Num<R>::tmax();
+    int best_g = -1;
+    scan_linear(sv, o, d, best_t, best_g, hc);
+    t = best_t;
+    return best_g;
+}
+
+// ------------------------------------------------------------------ parity kernels
+template <typename R, bool BVH, bool PRIMARY>
+__global__ void __launch_bounds__(256)
+intersect_kernel(SceneView<R> sv, size_t n, const double* __restrict__ a, const double* __restrict__ b,
+                 int32_t* __restrict__ object_id, int32_t* __restrict__ prim_id, double* __restrict__ t_out) {
+    // every lane of a wave runs the scan (wave-uniform loads, wave votes); lanes past n are masked at the store
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t j = i < n ? i : n - 1;
+    V3<R> o, d;
+    if (PRIMARY) {
+        o = mk<R>(sv.cam_o[0], sv.cam_o[1], sv.cam_o[2]);
+        d = camera_dir<R>(sv, (R)a[j], (R)b[j]);
+    } else {
+        o = mk<R>((R)a[3 * j], (R)a[3 * j + 1], (R)a[3 * j + 2]);
+        d = mk<R>((R)b[3 * j], (R)b[3 * j + 1], (R)b[3 * j + 2]);
+    }
+    HitCounters hc{0, 0};
+    R t;
+    int g = closest_hit<R, BVH>(sv, o, d, t, hc);
+    if (i < n) {
+        if (g >= 0) {
+            object_id[i] = sv.shade[g].object_id;
+            prim_id[i] = sv.shade[g].prim_id;
+            t_out[i] = (double)t;
+        } else {
+            object_id[i] = -1;
+            prim_id[i] = -1;
+            t_out[i] = __builtin_inf();
+        }
+    }
+}
+
+// ------------------------------------------------------------------ fused renderer
+// Work item = (pixel, chunk of consecutive sample indices).  Items are handed
+// out through one global counter; the lanes of a wave that need an item at the
+// same time share one atomic (ballot + popcount + lane rank).
+template <typename R, bool BVH>
+__global__ void __launch_bounds__(256)
+render_fused(SceneView<R> sv, RenderParams rp) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_pixels = rp.width * rp.height;
+
+    bool have_item = false, alive = false, exhausted = false;
+    uint32_t pixel = 0, pixkey = 0, s_cur = 0, s_end = 0;
+    V3<R> acc = mk<R>(0, 0, 0);      // radiance sum of the current item
+    V3<R> radiance = mk<R>(0, 0, 0); // radiance of the current sample
+    Path<R> path;
+    path.o = path.d = path.beta = mk<R>(0, 0, 0);
+    path.depth = 0;
+    path.smp = Sampler{0, 0, 0, 0, 4};
+
+    // wave-uniform event counters (live in SGPRs)
+    uint32_t c_rays = 0, c_nonfinite = 0, c_samples = 0;
+    HitCounters hc{0, 0};
+    BounceCounters bc{{0, 0, 0, 0, 0}};
+
+    for (;;) {
+        // -- a finished path: close the sample, and the item after its last sample
+        if (!alive && have_item && s_cur == s_end) {
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 0], (float)acc.x);
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 1], (float)acc.y);
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 2], (float)acc.z);
+            have_item = false;
+        }
+        const bool need = !alive && !have_item && !exhausted;
+        const unsigned long long need_mask = __ballot(need);
+        if (need_mask) {
+            const uint32_t cnt = (uint32_t)__popcll(need_mask);
+            const int leader = __ffsll((long long)need_mask) - 1;
+            unsigned long long base = 0;
+            if ((int)lane == leader) base = atomicAdd(rp.work_counter, (unsigned long long)cnt);
+            uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader);
+            uint32_t bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
+            base = ((unsigned long long)bhi << 32) | blo;
+            if (need) {
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+                unsigned long long w = base + rank;
+                if (w < rp.n_items) {
+                    uint32_t w32 = (uint32_t)w;  // n_items < 2^32 (checked by the launcher)
+                    uint32_t chunk = w32 / n_pixels;
+                    pixel = w32 - chunk * n_pixels;
+                    pixkey = pixel_key(rp.seed_lo, rp.seed_hi, pixel);
+                    uint32_t first = chunk * rp.chunk;
+                    uint32_t last = first + rp.chunk;
+                    if (last > rp.n_samples) last = rp.n_samples;
+                    s_cur = rp.sample_begin + first;
+                    s_end = rp.sample_begin + last;
+                    acc = mk<R>(0, 0, 0);
+                    have_item = true;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (__ballot(!exhausted) == 0ull) break;
+
+        // -- raygen: the head of the sample loop, src/renderer.rs:118-122
+        // (event counters are wave-uniform: they are bumped by ballots taken
+        // outside the divergent regions, so they stay in scalar registers)
+        const bool gen = !alive && have_item;
+        c_samples += (uint32_t)__popcll(__ballot(gen));
+        if (gen) {
+            sampler_start(path.smp, rp, pixkey, s_cur);
+            s_cur += 1;
+            R u_off, v_off;
+            get_2d<R>(path.smp, rp, u_off, v_off);
+            uint32_t py = pixel / rp.width;
+            uint32_t px = pixel - py * rp.width;
+            R u = ((R)px + u_off + R(0.5)) / (R)rp.width;
+            R v = R(1) - ((R)py + v_off + R(0.5)) / (R)rp.height;
+            path.o = mk<R>(sv.cam_o[0], sv.cam_o[1], sv.cam_o[2]);
+            path.d = camera_dir<R>(sv, u, v);
+            path.beta = mk<R>(1, 1, 1);
+            path.depth = 0;
+            radiance = mk<R>(0, 0, 0);
+            alive = true;
+        }
+
+        // -- one bounce: closest hit + shading, src/tracers/utils.rs:35-88
+        c_rays += (uint32_t)__popcll(__ballot(alive));
+        int scattered = -1;  // material type whose scatter was evaluated this iteration
+        bool ended_bad = false;
+        if (alive) {
+            R t;
+            int g = closest_hit<R, BVH>(sv, path.o, path.d, t, hc);
+            bool cont = false;
+            if (g >= 0) cont = shade_bounce<R>(sv, rp, path, g, t, radiance, scattered);
+            if (!cont) {
+                alive = false;
+                ended_bad = !(isfinite(radiance.x) && isfinite(radiance.y) && isfinite(radiance.z));
+                acc = acc + radiance;
+            }
+        }
+        c_nonfinite += (uint32_t)__popcll(__ballot(ended_bad));
+#pragma unroll
+        for (int k = 1; k < 5; ++k) bc.bounce[k] += (uint32_t)__popcll(__ballot(scattered == k));
+    }
+    if (!BVH) hc.prim_tests = c_rays * (uint32_t)sv.n_prims;  // a linear scan tests every primitive
+
+    if (lane == 0) {
+        atomicAdd(&rp.counters[COUNTER_RAYS], (unsigned long long)c_rays);
+        atomicAdd(&rp.counters[COUNTER_PRIM_TESTS], (unsigned long long)hc.prim_tests);
+        atomicAdd(&rp.counters[COUNTER_NODE_TESTS], (unsigned long long)hc.node_tests);
+        for (int k = 0; k < 5; ++k)
+            atomicAdd(&rp.counters[COUNTER_BOUNCE0 + k], (unsigned long long)bc.bounce[k]);
+        atomicAdd(&rp.counters[COUNTER_NONFINITE], (unsigned long long)c_nonfinite);
+        atomicAdd(&rp.counters[COUNTER_SAMPLES], (unsigned long long)c_samples);
+    }
+}
+
+// ------------------------------------------------------------------ post-process
+// src/renderer.rs:39-71,128-136 in f64 (the reference's arithmetic type); one
+// thread per colour component.
+__global__ void __launch_bounds__(256)
+postprocess_kernel(const float* __restrict__ sum, double inv_spp, PostParams pp, size_t n_components,
+                   uint8_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_components) return;
+    double c = (double)sum[i] * inv_spp;
+    if (pp.tone_mapping == 1) c = c / (c + 1.0);
+    if (pp.gamma) c = ::pow(c, 1.0 / 2.2);
+    if (pp.has_wb) c = c * pp.wb[i % 3];
+    double s = c * 255.0;
+    // Rust: (c * 255.0).min(255.0) as u8 -- min drops a NaN operand, the cast saturates
+    double m = (s != s) ? 255.0 : (s < 255.0 ? s : 255.0);
+    out[i] = m <= 0.0 ? (uint8_t)0 : (uint8_t)m;
+}
+
+// ------------------------------------------------------------------ launchers
+template <typename R>
+static hipError_t launch_intersect_t(const SceneView<R>& sv, bool primary, size_t n, const double* a,
+                                     const double* b, int32_t* oid, int32_t* pid, double* t,
+                                     hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n + 255) / 256));
+    if (primary)
+        hipLaunchKernelGGL((intersect_kernel<R, false, true>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+    else
+        hipLaunchKernelGGL((intersect_kernel<R, false, false>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+    return hipGetLastError();
+}
+
+hipError_t launch_intersect(const SceneView<float>& sv, bool primary, size_t n, const double* a,
+                            const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s) {
+    return launch_intersect_t<float>(sv, primary, n, a, b, oid, pid, t, s);
+}
+hipError_t launch_intersect(const SceneView<double>& sv, bool primary, size_t n, const double* a,
+                            const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s) {
+    return launch_intersect_t<double>(sv, primary, n, a, b, oid, pid, t, s);
+}
+
+template <typename R>
+static hipError_t launch_render_fused_t(const SceneView<R>& sv, const RenderParams& rp, int n_blocks,
+                                        hipStream_t stream) {
+    hipLaunchKernelGGL((render_fused<R, false>), dim3(n_blocks), dim3(256), 0, stream, sv, rp);
+    return hipGetLastError();
+}
+hipError_t launch_render_fused(const SceneView<float>& sv, const RenderParams& rp, int n_blocks, hipStream_t s) {
+    return launch_render_fused_t<float>(sv, rp, n_blocks, s);
+}
+hipError_t launch_render_fused(const SceneView<double>& sv, const RenderParams& rp, int n_blocks, hipStream_t s) {
+    return launch_render_fused_t<double>(sv, rp, n_blocks, s);
+}
+
+hipError_t launch_postprocess(const float* sum, double inv_spp, const PostParams& pp, size_t n_components,
+                              uint8_t* out, hipStream_t stream) {
+    if (n_components == 0) return hipSuccess;
+    dim3 block(256), grid((unsigned)((n_components + 255) / 256));
+    hipLaunchKernelGGL(postprocess_kernel, grid, block, 0, stream, sum, inv_spp, pp, n_components, out);
+    return hipGetLastError();
+}
+
+}  // namespace rrt

@@ -1,0 +1,29 @@
+// Host-callable launch wrappers of the kernels in rrt_kernels.hip / rrt_lbvh.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rrt_types.hpp"
+
+namespace rrt {
+
+struct PostParams {
+    int32_t tone_mapping;  // 0 none, 1 reinhard
+    int32_t gamma;
+    int32_t has_wb;
+    int32_t pad;
+    double wb[3];
+};
+
+// a, b: PRIMARY ? (u[n], v[n]) : (origins[3n], dirs[3n]); all pointers are device memory
+hipError_t launch_intersect(const SceneView<float>& sv, bool primary, size_t n, const double* a,
+                            const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s);
+hipError_t launch_intersect(const SceneView<double>& sv, bool primary, size_t n, const double* a,
+                            const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s);
+
+hipError_t launch_render_fused(const SceneView<float>& sv, const RenderParams& rp, int n_blocks, hipStream_t s);
+hipError_t launch_render_fused(const SceneView<double>& sv, const RenderParams& rp, int n_blocks, hipStream_t s);
+
+hipError_t launch_postprocess(const float* sum, double inv_spp, const PostParams& pp, size_t n_components,
+                              uint8_t* out, hipStream_t stream);
+
+}  // namespace rrt

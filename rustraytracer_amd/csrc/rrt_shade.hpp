@@ -1,0 +1,161 @@
+// Path state and the per-bounce shading step (materials, Russian roulette).
+#pragma once
+#include "rrt_device.hpp"
+
+namespace rrt {
+
+template <typename R>
+struct Path {
+    V3<R> o, d;     // current ray
+    V3<R> beta;     // throughput (src/tracers/utils.rs:24)
+    uint32_t depth; // loop counter of generate_camera_vertices (src/tracers/utils.rs:35)
+    Sampler smp;
+};
+
+// reflect / refract / fresnel: src/math.rs:133-160
+template <typename R>
+RRT_DEV V3<R> reflect(V3<R> v, V3<R> n) {
+    R k = R(2) * dot(v, n);
+    return mk<R>(v.x - n.x * k, v.y - n.y * k, v.z - n.z * k);
+}
+
+template <typename R>
+RRT_DEV R fresnel(R cos_i, R eta_i, R eta_t) {
+    R ratio = eta_i / eta_t;
+    R sin2_t = ratio * ratio * (R(1) - cos_i * cos_i);
+    if (sin2_t > R(1)) return R(1);
+    R cos_t = Num<R>::sqrt(R(1) - sin2_t);
+    R r_ortho = (eta_t * cos_i - eta_i * cos_t) / (eta_t * cos_i + eta_i * cos_t);
+    R r_parallel = (eta_i * cos_i - eta_t * cos_t) / (eta_i * cos_i + eta_t * cos_t);
+    return (r_ortho * r_ortho + r_parallel * r_parallel) * R(0.5);
+}
+
+// spherical_to_world over local_coordinate_system (src/math.rs:162-179) with
+// sin/cos of theta and phi already known.
+template <typename R>
+RRT_DEV V3<R> to_world(R sin_t, R cos_t, R sin_p, R cos_p, V3<R> w) {
+    V3<R> a = Num<R>::abs(w.x) > R(0.9) ? mk<R>(0, 1, 0) : mk<R>(1, 0, 0);
+    V3<R> u = normalize(cross(w, a));
+    V3<R> v = normalize(cross(w, u));
+    R cu = sin_t * cos_p, cv = sin_t * sin_p;
+    return mk<R>(u.x * cu + v.x * cv + w.x * cos_t, u.y * cu + v.y * cv + w.y * cos_t,
+                 u.z * cu + v.z * cv + w.z * cos_t);
+}
+
+struct BounceCounters {
+    uint32_t bounce[5];
+};
+
+// One iteration of the loop body of generate_camera_vertices AFTER the
+// closest-hit query (src/tracers/utils.rs:41-87) for a path that hit primitive
+// g at distance t.  Adds emitted radiance to `radiance` when the vertex is an
+// emitter (connect with s = 0, src/tracers/utils.rs:115-121).  Returns true if
+// the path continues with the new ray in `p`; `scattered` receives the type of
+// the material whose scatter was evaluated (left alone if none was).
+//
+// The throughput factor cos * bxdf / pdf (utils.rs:76-82) is applied in its
+// reduced form, which is the same number wherever pdf > 1e-6:
+//   Lambertian      (|c| albedo/pi) / (c/pi)                 = albedo
+//   PhongSpecular   |d.n| spec (s+2)/(2pi) c^s / (c^s (s+1)/(2pi)) = spec |d.n| (s+2)/(s+1)
+//   IdealReflector  c (1/c) / 1                              = 1   (0 if d.n <= 1e-6)
+//   IdealDielectric reflect: c (F/c) / F = 1; refract: c ((1-F)/(c eta^2)) / (1-F) = 1/eta^2
+//                   (0 if |d.n| < 1e-6)
+// A path whose throughput became exactly zero is dropped: it can only add zero.
+template <typename R>
+RRT_DEV bool shade_bounce(const SceneView<R>& sv, const RenderParams& rp, Path<R>& p, int g, R t,
+                          V3<R>& radiance, int& scattered) {
+    const ShadeRec<R> sh = sv.shade[g];
+    const MatRec<R> m = sv.mats[sh.object_id];
+    V3<R> P = mk<R>(p.o.x + t * p.d.x, p.o.y + t * p.d.y, p.o.z + t * p.d.z);
+    V3<R> n = mk<R>(sh.nx, sh.ny, sh.nz);
+    if (sh.type == PRIM_SPHERE) {  // (point - center) / radius, src/shapes/sphere.rs:87
+        R inv_r = Num<R>::rcp(sh.w);
+        n = mk<R>((P.x - sh.nx) * inv_r, (P.y - sh.ny) * inv_r, (P.z - sh.nz) * inv_r);
+    }
+    if (m.type == MAT_EMISSIVE) {
+        // an Emissive surface ends the path either way: as an emitter
+        // (utils.rs:52-54) or because its scatter returns None (material.rs:44-46)
+        radiance.x += p.beta.x * m.r;
+        radiance.y += p.beta.y * m.g;
+        radiance.z += p.beta.z * m.b;
+        return false;
+    }
+    // Russian roulette (utils.rs:56-64): one 1D draw per bounce, used or not
+    const bool rr = p.depth > rp.min_depth;
+    R xi = get_1d<R>(p.smp, rp, rr);
+    if (rr) {
+        R q = fmin(fmax(fmax(p.beta.x, p.beta.y), p.beta.z), R(1));
+        if (xi > q) return false;
+        R inv_q = R(1) / q;
+        p.beta = p.beta * inv_q;
+    }
+    V3<R> dir;
+    if (m.type == MAT_LAMBERTIAN) {  // src/material.rs:67-91
+        scattered = MAT_LAMBERTIAN;
+        R u, v;
+        get_2d<R>(p.smp, rp, u, v);
+        R cos_t = Num<R>::sqrt(R(1) - u);  // theta = acos(sqrt(1 - u))
+        R sin_t = Num<R>::sqrt(u);
+        R sp, cp;
+        Num<R>::sincos2pi(v, sp, cp);
+        dir = to_world(sin_t, cos_t, sp, cp, n);
+        R pdf = dot(dir, n) * Num<R>::inv_pi();
+        if (pdf <= Num<R>::eps()) return false;
+        p.beta = mk<R>(p.beta.x * m.r, p.beta.y * m.g, p.beta.z * m.b);
+    } else if (m.type == MAT_PHONG) {  // src/material.rs:104-142
+        scattered = MAT_PHONG;
+        V3<R> refl = reflect(p.d, n);
+        R u, v;
+        get_2d<R>(p.smp, rp, u, v);
+        R s = m.param;
+        R cos_t = Num<R>::pow(u, R(1) / (s + R(1)));
+        R sin_t = Num<R>::sqrt(fmax(R(1) - cos_t * cos_t, R(0)));
+        R sp, cp;
+        Num<R>::sincos2pi(v, sp, cp);
+        dir = to_world(sin_t, cos_t, sp, cp, refl);
+        R c = dot(dir, refl);
+        R pdf = Num<R>::pow(c, s) * (s + R(1)) * Num<R>::inv_pi() * R(0.5);
+        if (!(pdf > Num<R>::eps())) return false;
+        R w = Num<R>::abs(dot(dir, n)) * (s + R(2)) / (s + R(1));
+        p.beta = mk<R>(p.beta.x * m.r * w, p.beta.y * m.g * w, p.beta.z * m.b * w);
+    } else if (m.type == MAT_REFLECTOR) {  // src/material.rs:156-181
+        scattered = MAT_REFLECTOR;
+        dir = reflect(p.d, n);
+        if (!(dot(dir, n) > Num<R>::eps())) return false;
+    } else {  // IdealDielectric, src/material.rs:193-284
+        scattered = MAT_DIELECTRIC;
+        R dn = dot(p.d, n);
+        const bool inside = dn > R(0);
+        V3<R> on = inside ? mk<R>(-n.x, -n.y, -n.z) : n;
+        R eta_i = inside ? m.param : R(1);
+        R eta_t = inside ? R(1) : m.param;
+        R eta = eta_i / eta_t;
+        R cos_theta = -dot(p.d, on);
+        R r = get_1d<R>(p.smp, rp, true);
+        R F = fresnel<R>(cos_theta, eta_i, eta_t);
+        R pdf, w;
+        if (r < F) {
+            dir = reflect(p.d, on);
+            pdf = F;
+            w = R(1);
+        } else {
+            R sin2_t = (R(1) - cos_theta * cos_theta) * eta * eta;  // refract, src/math.rs:137-146
+            if (sin2_t > R(1)) return false;
+            R cos_t2 = Num<R>::sqrt(R(1) - sin2_t);
+            R k = eta * cos_theta - cos_t2;
+            dir = mk<R>(eta * p.d.x + k * on.x, eta * p.d.y + k * on.y, eta * p.d.z + k * on.z);
+            pdf = R(1) - F;
+            w = R(1) / (eta * eta);
+        }
+        if (pdf <= Num<R>::eps()) return false;
+        if (Num<R>::abs(dot(dir, n)) < Num<R>::eps()) return false;
+        p.beta = p.beta * w;
+    }
+    p.o = P;
+    p.d = dir;
+    p.depth += 1;
+    if (p.depth >= rp.max_depth) return false;  // `for depth in 0..max_depth`
+    return !(p.beta.x == R(0) && p.beta.y == R(0) && p.beta.z == R(0));
+}
+
+}  // namespace rrt

@@ -1,0 +1,113 @@
+// Device-side data layout of a flattened scene, shared by host set-up code and kernels.
+//
+// A scene is uploaded once per device in two precisions (R = float, double).
+// Records are derived from the f64 scene description on the host, in f64, and
+// rounded to R once, so the f32 kernels do not inherit f32 set-up error.
+#pragma once
+#include <stdint.h>
+
+namespace rrt {
+
+enum : int { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_TRIANGLE = 2, PRIM_QUAD = 3 };
+enum : int { MAT_EMISSIVE = 0, MAT_LAMBERTIAN = 1, MAT_PHONG = 2, MAT_REFLECTOR = 3, MAT_DIELECTRIC = 4 };
+
+// Intersection record of one primitive: everything the per-ray test reads, in
+// the order the reference's linear scan visits primitives.  In the small-scene
+// kernels the index into this table is wave-uniform, so a record travels
+// through the scalar cache into SGPRs and costs no vector register.
+//
+//   triangle / quad (plane form of Moller-Trumbore / Lagae-Dutre, see intersect.hpp)
+//     f[0..2] n = e01 x e03 (unnormalised)       f[3]  n . v0
+//     f[4..6] A,  f[7]  cA   alpha = A . P + cA   (coefficient of P - v0 on e01)
+//     f[8..10] B, f[11] cB   beta  = B . P + cB   (coefficient on e03)
+//     quad only, second corner v2:
+//     f[12..14] A2, f[15] cA2   alpha' on e23 = v3 - v2
+//     f[16..18] B2, f[19] cB2   beta'  on e21 = v1 - v2
+//     f[20..22] n2 = e23 x e21
+//   sphere   f[0..2] centre, f[3] radius, f[4] radius^2
+//   plane    f[0..2] unit normal, f[3] normal . point
+template <typename R>
+struct PrimRec {
+    R f[23];
+    int32_t type;
+};
+
+// What shading needs from the primitive that was hit (one gather per bounce).
+//   triangle / quad / plane: n = the unit normal the reference reports
+//   sphere: n = centre, w = radius (normal = (P - centre) / radius)
+template <typename R>
+struct ShadeRec {
+    R nx, ny, nz, w;
+    int32_t object_id;
+    int32_t prim_id;
+    int32_t type;
+    int32_t pad;
+};
+
+// One material per object (src/material.rs:286-315).
+template <typename R>
+struct MatRec {
+    R r, g, b;   // emission / albedo / specular
+    R param;     // shininess / index of refraction
+    int32_t type;
+    int32_t emitter;  // |emission| > 1e-6  (src/tracers/utils.rs:52)
+    int32_t pad[2];
+};
+
+// LBVH node (see lbvh.hip).  Children < 0 encode leaves: ~child = sorted
+// primitive slot.  Boxes are stored padded outward so that an f32 slab test
+// never rejects a box the exact arithmetic would enter.
+struct BvhNode {
+    float lo[3];
+    int32_t left;
+    float hi[3];
+    int32_t right;
+};
+
+template <typename R>
+struct SceneView {
+    R cam_o[3];    // camera origin
+    R cam_ll[3];   // lower_left_corner - origin
+    R cam_h[3];    // horizontal
+    R cam_v[3];    // vertical
+    const PrimRec<R>* prims;   // n_prims, scan order
+    const ShadeRec<R>* shade;  // n_prims
+    const MatRec<R>* mats;     // n_objects
+    int32_t n_prims;
+    int32_t n_objects;
+    // acceleration structure (n_bvh_prims == 0: linear scan over all prims)
+    const BvhNode* nodes;
+    const int32_t* bvh_prim;   // sorted slot -> scan-order primitive index
+    const int32_t* linear_prim; // primitives kept out of the tree (planes), scan order
+    int32_t n_bvh_prims;
+    int32_t n_linear_prims;
+};
+
+struct RenderParams {
+    uint32_t width, height;
+    uint32_t sampler_type, spp, x_strata, y_strata;
+    uint32_t x_shift;          // log2(x_strata) if it is a power of two, else 0xffffffff
+    uint32_t perm_mask;        // next_pow2(spp) - 1
+    uint32_t min_depth, max_depth;
+    uint32_t sample_begin;     // first per-pixel sample index of this call
+    uint32_t n_samples;        // samples per pixel traced by this call
+    uint32_t chunk;            // samples per work item
+    uint32_t n_chunks;         // work items per pixel
+    uint64_t n_items;          // n_chunks * width * height
+    uint32_t seed_lo, seed_hi;
+    float* accum;              // width*height*3 radiance sums (atomicAdd target)
+    unsigned long long* counters;  // see COUNTER_* below
+    unsigned long long* work_counter;
+};
+
+enum : int {
+    COUNTER_RAYS = 0,
+    COUNTER_PRIM_TESTS = 1,
+    COUNTER_NODE_TESTS = 2,
+    COUNTER_BOUNCE0 = 3,   // +material type, 5 entries
+    COUNTER_NONFINITE = 8,
+    COUNTER_SAMPLES = 9,
+    COUNTER_COUNT = 16
+};
+
+}  // namespace rrt
