@@ -202,6 +202,15 @@ int rrt_postprocess(rrt_backend* backend, const float* rgb_sum_dev_or_host, uint
 int rrt_render(rrt_backend* backend, const rrt_scene* scene, const rrt_render_desc* desc,
                const rrt_post_desc* post, uint8_t* rgb8_host, rrt_stats* stats);
 
+/* The numbers the device sampler hands to one camera sample, in the order the
+ * path tracer asks for them on a diffuse path: get_2d (pixel jitter), get_1d,
+ * get_2d, get_1d, get_2d -- i.e. the four stratified dimensions of
+ * StratifiedSampler (src/sampler.rs:135-151) followed by one plain uniform
+ * pair.  out receives 8 floats per sample index in [sample_begin, sample_end)
+ * of pixel `pixel` (host memory).  Lets a test check on the device that every
+ * stratum of every dimension is visited exactly once per pixel. */
+int rrt_sampler_values(rrt_backend* backend, const rrt_render_desc* desc, uint32_t pixel, float* out_host);
+
 #ifdef __cplusplus
 }
 #endif

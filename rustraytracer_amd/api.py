@@ -119,6 +119,14 @@ class Backend:
                                                                _ptr(rgb_sum), C.byref(st)))
         return rgb_sum, st.as_dict()
 
+    def sampler_values(self, render_desc, pixel):
+        """Device sampler output for every sample index of the desc's range: float32 [n, 8]
+        = get_2d, get_1d, get_2d, get_1d (the four stratified dimensions), get_2d (uniform)."""
+        n = int(render_desc.sample_end - render_desc.sample_begin)
+        out = np.empty((n, 8), dtype=np.float32)
+        _abi.check(self._lib, self._lib.rrt_sampler_values(self.handle, C.byref(render_desc), int(pixel), _ptr(out)))
+        return out
+
     def postprocess(self, rgb_sum, spp_divisor, post_desc, out=None):
         """mean -> tone map -> gamma -> white balance -> u8.  Returns uint8 [H, W, 3]."""
         if isinstance(rgb_sum, np.ndarray):

@@ -334,6 +334,39 @@ int validate_render_desc(const rrt_render_desc* d) {
     return RRT_OK;
 }
 
+// Kernel-side view of a validated render description.
+rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
+    const size_t n_pixels = (size_t)desc->width * desc->height;
+    rrt::RenderParams rp;
+    std::memset(&rp, 0, sizeof(rp));
+    rp.width = desc->width;
+    rp.height = desc->height;
+    rp.sampler_type = desc->sampler_type;
+    rp.spp = desc->spp;
+    rp.x_strata = desc->x_strata ? desc->x_strata : 1;
+    rp.y_strata = desc->y_strata ? desc->y_strata : 1;
+    rp.x_shift = 0xffffffffu;
+    if ((rp.x_strata & (rp.x_strata - 1)) == 0) {
+        rp.x_shift = 0;
+        while ((1u << rp.x_shift) < rp.x_strata) rp.x_shift++;
+    }
+    rp.perm_mask = next_pow2_mask(desc->spp);
+    rp.min_depth = desc->min_depth;
+    rp.max_depth = desc->max_depth;
+    rp.sample_begin = (uint32_t)desc->sample_begin;
+    rp.n_samples = (uint32_t)(desc->sample_end - desc->sample_begin);
+    // samples per work item: enough items to balance the tail, few enough to keep
+    // the per-item atomics and the 32-bit item index negligible / valid
+    uint32_t chunk = rp.n_samples < 128 ? rp.n_samples : 128;
+    while ((uint64_t)((rp.n_samples + chunk - 1) / chunk) * n_pixels >= (1ull << 31)) chunk *= 2;
+    rp.chunk = chunk;
+    rp.n_chunks = (rp.n_samples + chunk - 1) / chunk;
+    rp.n_items = (uint64_t)rp.n_chunks * n_pixels;
+    rp.seed_lo = (uint32_t)desc->seed;
+    rp.seed_hi = (uint32_t)(desc->seed >> 32);
+    return rp;
+}
+
 }  // namespace
 
 extern "C" {
@@ -475,33 +508,7 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         HIP_TRY(hipMemsetAsync(d_accum, 0, n_pixels * 3 * sizeof(float), be->stream));
     }
 
-    rrt::RenderParams rp;
-    std::memset(&rp, 0, sizeof(rp));
-    rp.width = desc->width;
-    rp.height = desc->height;
-    rp.sampler_type = desc->sampler_type;
-    rp.spp = desc->spp;
-    rp.x_strata = desc->x_strata ? desc->x_strata : 1;
-    rp.y_strata = desc->y_strata ? desc->y_strata : 1;
-    rp.x_shift = 0xffffffffu;
-    if ((rp.x_strata & (rp.x_strata - 1)) == 0) {
-        rp.x_shift = 0;
-        while ((1u << rp.x_shift) < rp.x_strata) rp.x_shift++;
-    }
-    rp.perm_mask = next_pow2_mask(desc->spp);
-    rp.min_depth = desc->min_depth;
-    rp.max_depth = desc->max_depth;
-    rp.sample_begin = (uint32_t)desc->sample_begin;
-    rp.n_samples = (uint32_t)(desc->sample_end - desc->sample_begin);
-    // samples per work item: enough items to balance the tail, few enough to keep
-    // the per-item atomics and the 32-bit item index negligible / valid
-    uint32_t chunk = rp.n_samples < 128 ? rp.n_samples : 128;
-    while ((uint64_t)((rp.n_samples + chunk - 1) / chunk) * n_pixels >= (1ull << 31)) chunk *= 2;
-    rp.chunk = chunk;
-    rp.n_chunks = (rp.n_samples + chunk - 1) / chunk;
-    rp.n_items = (uint64_t)rp.n_chunks * n_pixels;
-    rp.seed_lo = (uint32_t)desc->seed;
-    rp.seed_hi = (uint32_t)(desc->seed >> 32);
+    rrt::RenderParams rp = make_render_params(desc);
     rp.accum = d_accum;
     rp.counters = be->d_counters;
     rp.work_counter = be->d_counters + rrt::COUNTER_COUNT;
@@ -545,6 +552,22 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         for (int k = 0; k < 5; ++k) stats->bounces[k] = counters[rrt::COUNTER_BOUNCE0 + k];
         stats->nonfinite = counters[rrt::COUNTER_NONFINITE];
     }
+    return RRT_OK;
+}
+
+int rrt_sampler_values(rrt_backend* be, const rrt_render_desc* desc, uint32_t pixel, float* out_host) {
+    int rc = check_backend(be);
+    if (rc != RRT_OK) return rc;
+    if (!out_host) return fail(RRT_ERR_INVALID, "out is NULL");
+    if ((rc = validate_render_desc(desc)) != RRT_OK) return rc;
+    if (pixel >= desc->width * desc->height) return fail(RRT_ERR_INVALID, "pixel %u outside the image", pixel);
+    rrt::RenderParams rp = make_render_params(desc);
+    DevBuf buf;
+    const size_t bytes = (size_t)rp.n_samples * 8 * sizeof(float);
+    HIP_TRY(buf.alloc(bytes));
+    HIP_TRY(rrt::launch_sampler_values(rp, pixel, (float*)buf.p, be->stream));
+    HIP_TRY(hipMemcpyAsync(out_host, buf.p, bytes, hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipStreamSynchronize(be->stream));
     return RRT_OK;
 }
 

@@ -270,7 +270,16 @@ RRT_DEV bool prim_test(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R bes
     if (type == PRIM_SPHERE) {  // src/shapes/sphere.rs:58-96
         V3<R> l = mk<R>(f[0] - o.x, f[1] - o.y, f[2] - o.z);
         R t_ca = dot(l, d);
-        R d2 = dot(l, l) - t_ca * t_ca;
+        R d2;
+        if (sizeof(R) == 4) {
+            // |l - t_ca d|^2 equals |l|^2 - t_ca^2 for unit d; formed this way the
+            // difference of two large squares is never taken, which in f32 would
+            // lose the silhouette of a small sphere seen from far away
+            V3<R> perp = mk<R>(l.x - t_ca * d.x, l.y - t_ca * d.y, l.z - t_ca * d.z);
+            d2 = dot(perp, perp);
+        } else {
+            d2 = dot(l, l) - t_ca * t_ca;
+        }
         R r2 = f[4];
         bool ok = !(d2 < R(0)) && !(d2 > r2);
         R t_hc = Num<R>::sqrt(r2 - d2);

@@ -176,6 +176,20 @@ render_fused(SceneView<R> sv, RenderParams rp) {
     }
 }
 
+// ------------------------------------------------------------------ sampler probe
+__global__ void __launch_bounds__(256) sampler_values_kernel(RenderParams rp, uint32_t pixel, float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rp.n_samples) return;
+    Sampler s;
+    sampler_start(s, rp, pixel_key(rp.seed_lo, rp.seed_hi, pixel), rp.sample_begin + i);
+    float* o = out + 8 * (size_t)i;
+    get_2d<float>(s, rp, o[0], o[1]);
+    o[2] = get_1d<float>(s, rp, true);
+    get_2d<float>(s, rp, o[3], o[4]);
+    o[5] = get_1d<float>(s, rp, true);
+    get_2d<float>(s, rp, o[6], o[7]);
+}
+
 // ------------------------------------------------------------------ post-process
 // src/renderer.rs:39-71,128-136 in f64 (the reference's arithmetic type); one
 // thread per colour component.
@@ -228,6 +242,12 @@ hipError_t launch_render_fused(const SceneView<float>& sv, const RenderParams& r
 }
 hipError_t launch_render_fused(const SceneView<double>& sv, const RenderParams& rp, int n_blocks, hipStream_t s) {
     return launch_render_fused_t<double>(sv, rp, n_blocks, s);
+}
+
+hipError_t launch_sampler_values(const RenderParams& rp, uint32_t pixel, float* out, hipStream_t stream) {
+    dim3 block(256), grid((rp.n_samples + 255) / 256);
+    hipLaunchKernelGGL(sampler_values_kernel, grid, block, 0, stream, rp, pixel, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_postprocess(const float* sum, double inv_spp, const PostParams& pp, size_t n_components,

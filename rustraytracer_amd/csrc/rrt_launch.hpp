@@ -23,6 +23,8 @@ hipError_t launch_intersect(const SceneView<double>& sv, bool primary, size_t n,
 hipError_t launch_render_fused(const SceneView<float>& sv, const RenderParams& rp, int n_blocks, hipStream_t s);
 hipError_t launch_render_fused(const SceneView<double>& sv, const RenderParams& rp, int n_blocks, hipStream_t s);
 
+hipError_t launch_sampler_values(const RenderParams& rp, uint32_t pixel, float* out, hipStream_t stream);
+
 hipError_t launch_postprocess(const float* sum, double inv_spp, const PostParams& pp, size_t n_components,
                               uint8_t* out, hipStream_t stream);
 

@@ -1,0 +1,93 @@
+"""Small analytic scenes shared by the CPU (oracle) and GPU tests."""
+import numpy as np
+
+from rustraytracer_amd import _abi, config
+
+
+def make_scene(prims, materials, look_from=(0, 0, 0), look_at=(0, 0, -1), vup=(0, 1, 0), vfov=60.0, aspect=1.0):
+    """prims: list of (type, object_id, prim_id, values); materials: list of (type, rgb, param)."""
+    p = np.zeros(len(prims), dtype=_abi.PRIM_DTYPE)
+    for i, (typ, oid, pid, vals) in enumerate(prims):
+        vals = np.asarray(vals, dtype=np.float64).reshape(-1)
+        p["type"][i], p["object_id"][i], p["prim_id"][i] = typ, oid, pid
+        p["v"][i, : len(vals)] = vals
+    m = np.zeros(len(materials), dtype=_abi.MATERIAL_DTYPE)
+    for i, (typ, rgb, param) in enumerate(materials):
+        m["type"][i], m["rgb"][i], m["param"][i] = typ, rgb, param
+    cam = config.perspective_camera(look_from, look_at, vup, vfov, aspect)
+    return config.FlatScene(cam, p, m)
+
+
+L = (3.0, 2.0, 1.0)
+
+
+def furnace():
+    """Camera at the centre of an emissive sphere of colour L: every sample is exactly L."""
+    return make_scene([(0, 0, 0, [0, 0, 0, 10.0])], [(_abi.MAT_EMISSIVE, L, 0.0)])
+
+
+def lambert_floor(albedo=(0.8, 0.5, 0.25)):
+    """A Lambertian plane under the camera inside an emissive sphere: rays that start on the
+    plane always reach the sphere, so a pixel that sees the plane is exactly albedo * L."""
+    return make_scene(
+        [(0, 0, 0, [0, 0, 0, 50.0]), (1, 1, 0, [0, -1, 0, 0, 1, 0])],
+        [(_abi.MAT_EMISSIVE, L, 0.0), (_abi.MAT_LAMBERTIAN, albedo, 0.0)],
+        look_from=(0, 0, 0), look_at=(0, -1, -0.2), vup=(0, 0, -1), vfov=40.0)
+
+
+def mirror_ball():
+    """An ideal-reflector sphere in front of the camera inside the emissive sphere: L everywhere."""
+    return make_scene(
+        [(0, 0, 0, [0, 0, 0, 50.0]), (0, 1, 0, [0, 0, -3, 1.0])],
+        [(_abi.MAT_EMISSIVE, L, 0.0), (_abi.MAT_REFLECTOR, (0, 0, 0), 0.0)])
+
+
+def glass_ball(ior=1.5):
+    """A dielectric sphere inside the emissive sphere.  Every refraction into the glass scales the
+    throughput by 1/eta^2 = ior^2 and every exit by 1/ior^2, reflections by 1: a path that leaves
+    the ball carries exactly L, a path cut off at max_depth carries 0."""
+    return make_scene(
+        [(0, 0, 0, [0, 0, 0, 50.0]), (0, 1, 0, [0, 0, -3, 1.0])],
+        [(_abi.MAT_EMISSIVE, L, 0.0), (_abi.MAT_DIELECTRIC, (0, 0, 0), ior)])
+
+
+def phong_floor(spec=(0.9, 0.6, 0.3), shininess=20.0):
+    return make_scene(
+        [(0, 0, 0, [0, 0, 0, 50.0]), (1, 1, 0, [0, -1, 0, 0, 1, 0])],
+        [(_abi.MAT_EMISSIVE, L, 0.0), (_abi.MAT_PHONG, spec, shininess)],
+        look_from=(0, 0, 0), look_at=(0, -1, -1), vup=(0, 0, -1), vfov=30.0)
+
+
+def all_prims_scene():
+    """One primitive of every type, several materials: exercises every branch of closest-hit."""
+    prims = [
+        (0, 0, 0, [0.0, 0.5, -4.0, 1.0]),                                       # sphere
+        (1, 1, 0, [0, -1, 0, 0, 1, 0]),                                           # floor plane
+        (2, 2, 0, [[-3, -1, -6], [-1, -1, -6], [-2, 2, -6]]),                    # triangle
+        (3, 3, 0, [[1, -1, -6], [3, -1, -6], [3, 1.5, -6], [1, 1.5, -6]]),       # quad
+        (3, 3, 1, [[1, -1, -6], [1, 1.5, -6], [1, 1.5, -3], [1, -1, -3]]),       # second face of "mesh" 3
+        (2, 3, 2, [[3, -1, -6], [3, -1, -3], [3, 1.5, -6]]),                     # triangle face of "mesh" 3
+        (0, 4, 0, [0, 0, 0, 30.0]),                                               # enclosing light
+    ]
+    mats = [(_abi.MAT_DIELECTRIC, (0, 0, 0), 1.5), (_abi.MAT_LAMBERTIAN, (0.6, 0.6, 0.6), 0.0),
+            (_abi.MAT_PHONG, (0.7, 0.7, 0.2), 8.0), (_abi.MAT_REFLECTOR, (0, 0, 0), 0.0),
+            (_abi.MAT_EMISSIVE, (1.0, 1.0, 1.0), 0.0)]
+    return make_scene(prims, mats, look_from=(0, 0.5, 2), look_at=(0, 0.2, -4), vfov=55.0)
+
+
+def secondary_rays(flat, O, n, seed):
+    """Rays that start ON scene surfaces (primary hit points) with random directions, plus the camera
+    rays themselves: the population the bounce loop feeds to closest-hit."""
+    rng = np.random.default_rng(seed)
+    u, v = rng.random(n), rng.random(n)
+    oid, pid, t = O.trace_primary(flat, u, v)
+    cam = flat.camera
+    p = (cam["lower_left_corner"] + u[:, None] * cam["horizontal"] + v[:, None] * cam["vertical"] - cam["origin"])
+    d = p / np.linalg.norm(p, axis=1, keepdims=True)
+    hit = oid >= 0
+    o2 = cam["origin"] + d[hit] * t[hit, None]
+    d2 = rng.normal(size=o2.shape)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    o_all = np.concatenate([np.broadcast_to(cam["origin"], d.shape), o2])
+    d_all = np.concatenate([d, d2])
+    return np.ascontiguousarray(o_all), np.ascontiguousarray(d_all)

@@ -1,0 +1,99 @@
+"""Closest-hit of the oracle: scan order, tie rule, golden vectors, independent cross-check."""
+import numpy as np
+
+import np_reference as NP
+import scenes_util as S
+from rustraytracer_amd import _abi
+
+
+def test_cornell_flattening(cornell):
+    # 6 mesh objects with 1, 6, 6, 3, 1, 1 quads (sizes of the LFS stubs), no triangle
+    assert cornell.n_prims == 18 and cornell.n_objects == 6
+    assert np.all(cornell.prims["type"] == _abi.PRIM_QUAD)
+    assert list(np.bincount(cornell.prims["object_id"])) == [1, 6, 6, 3, 1, 1]
+    for oid in range(6):
+        ids = cornell.prims["prim_id"][cornell.prims["object_id"] == oid]
+        assert list(ids) == list(range(len(ids)))
+    # light: 0.8 mm under the 0.5488 ceiling, centred at (-0.278, 0.28)
+    light = cornell.prims["v"][0].reshape(4, 3)
+    assert np.allclose(light[:, 2], 0.548) and np.allclose(light.mean(0)[:2], [-0.278, 0.280])
+    # boxes stand on the floor
+    for oid, top in ((1, 0.330), (2, 0.166)):
+        z = cornell.prims["v"][cornell.prims["object_id"] == oid].reshape(-1, 3)[:, 2]
+        assert abs(z.min()) < 1e-12 and abs(z.max() - top) < 1e-12
+    assert list(cornell.materials["type"]) == [0, 1, 1, 1, 1, 1]
+
+
+def test_smallpt_flattening(smallpt):
+    assert smallpt.n_prims == 9 and smallpt.n_objects == 9
+    assert list(smallpt.prims["type"]) == [0, 1, 1, 1, 1, 1, 1, 0, 0]
+    assert list(smallpt.materials["type"]) == [0, 1, 1, 1, 1, 1, 1, 3, 4]
+    assert smallpt.materials["param"][8] == 1.5
+
+
+def test_golden_primary_hits_reproduce(O, scenes, golden_hits):
+    for name, flat in scenes.items():
+        oid, pid, t = O.trace_primary(flat, golden_hits[f"{name}_u"], golden_hits[f"{name}_v"])
+        assert np.array_equal(oid, golden_hits[f"{name}_object_id"])
+        assert np.array_equal(pid, golden_hits[f"{name}_prim_id"])
+        assert np.array_equal(t, golden_hits[f"{name}_t"])
+        assert (oid >= 0).sum() > 0.9 * len(oid)
+
+
+def test_oracle_matches_numpy_restatement_primary(O, scenes, golden_hits):
+    for name, flat in scenes.items():
+        u, v = golden_hits[f"{name}_u"], golden_hits[f"{name}_v"]
+        o, d = NP.create_rays(flat.camera, u, v)
+        oid, pid, t = NP.scene_intersect(flat.prims, o, d)
+        assert np.array_equal(oid, golden_hits[f"{name}_object_id"])
+        assert np.array_equal(pid, golden_hits[f"{name}_prim_id"])
+        hit = oid >= 0
+        assert np.all(np.abs(t[hit] - golden_hits[f"{name}_t"][hit]) <= 1e-12 * np.abs(t[hit]))
+        assert np.all(np.isinf(t[~hit]))
+
+
+def test_oracle_matches_numpy_restatement_secondary(O, scenes):
+    flats = dict(scenes)
+    flats["all_prims"] = S.all_prims_scene()
+    for name, flat in flats.items():
+        o, d = S.secondary_rays(flat, O, 6000, seed=5)
+        a = O.intersect(flat, o, d)
+        b = NP.scene_intersect(flat.prims, o, d)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), name
+        hit = a[0] >= 0
+        assert np.all(np.abs(a[2][hit] - b[2][hit]) <= 1e-11 * np.abs(b[2][hit]))
+        assert len(set(a[0].tolist())) >= min(flat.n_objects, 4)  # the rays reach many objects
+
+
+def test_self_hit_is_cut_by_t_min(O, cornell):
+    # a ray leaving the floor does not re-hit the floor (t_min = 0.001, src/scene.rs:40)
+    oid, pid, t = O.intersect(cornell, [[-0.25, 0.3, 0.0]], [[0.0, 0.0, 1.0]])
+    assert (oid[0], pid[0]) == (0, 0) and abs(t[0] - 0.548) < 1e-12  # the light above
+
+
+def test_tie_rule(O):
+    """Equal t: sphere / plane / quad REPLACE an earlier hit (t > t_max rejects, so t == t_max passes),
+    triangles do not (t < t_max is strict)."""
+    quad = [[-1, -1, -2], [1, -1, -2], [1, 1, -2], [-1, 1, -2]]
+    tri = [[-1, -1, -2], [3, -1, -2], [-1, 3, -2]]
+    mats = [(_abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)] * 3
+    o, d = [[0.0, 0.0, 0.0]], [[0.0, 0.0, -1.0]]
+    two_quads = S.make_scene([(3, 0, 0, quad), (3, 1, 0, quad)], mats)
+    assert O.intersect(two_quads, o, d)[0][0] == 1
+    two_tris = S.make_scene([(2, 0, 0, tri), (2, 1, 0, tri)], mats)
+    assert O.intersect(two_tris, o, d)[0][0] == 0
+    quad_then_tri = S.make_scene([(3, 0, 0, quad), (2, 1, 0, tri)], mats)
+    assert O.intersect(quad_then_tri, o, d)[0][0] == 0
+    tri_then_quad = S.make_scene([(2, 0, 0, tri), (3, 1, 0, quad)], mats)
+    assert O.intersect(tri_then_quad, o, d)[0][0] == 1
+    tri_quad_tri_plane = S.make_scene(
+        [(2, 0, 0, tri), (3, 1, 0, quad), (2, 2, 0, tri), (1, 0, 0, [0, 0, -2, 0, 0, 1])], mats)
+    assert O.intersect(tri_quad_tri_plane, o, d)[0][0] == 0 and O.intersect(tri_quad_tri_plane, o, d)[1][0] == 0
+
+
+def test_empty_scene_and_all_miss(O):
+    empty = S.make_scene([], [])
+    oid, pid, t = O.trace_primary(empty, [0.5], [0.5])
+    assert oid[0] == -1 and pid[0] == -1 and np.isinf(t[0])
+    behind = S.make_scene([(0, 0, 0, [0, 0, 5.0, 1.0])], [(_abi.MAT_EMISSIVE, (1, 1, 1), 0)])
+    assert O.trace_primary(behind, [0.5], [0.5])[0][0] == -1
