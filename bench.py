@@ -45,7 +45,7 @@ def cpu_baseline(flat, threads):
     from oracle import oracle_py as O
     from rustraytracer_amd import config
 
-    rc = config.stratified_config(500, 500, 16, 16)  # same scene / image / tracer, 256 spp
+    rc = config.stratified_config(500, 500, 32, 32)  # same scene / image / tracer, 1024 spp
     t0 = time.perf_counter()
     _, st = O.render_accumulate(flat, rc.render_desc(), n_threads=threads)
     dt = time.perf_counter() - t0
@@ -55,7 +55,7 @@ def cpu_baseline(flat, threads):
         "mrays_per_s": st["rays"] / dt / 1e6,
         "cores": threads,
         "kind": "port",
-        "sample": "Cornell Box 500x500 stratified 16x16 = 256 spp (64.0 M samples), f64 C restatement of the "
+        "sample": "Cornell Box 500x500 stratified 32x32 = 1024 spp (256 M samples), f64 C restatement of the "
                   "reference renderer, 16x16 tiles over %d threads, %.1f s" % (threads, dt),
     }
 

@@ -584,6 +584,7 @@ static v3 mat_bxdf(const rrt_material* m, const ray_t* ray_in, const ray_t* ray_
 /* ------------------------------------------------------------ tracers/ */
 typedef struct {
     uint64_t rays, bounces[5], nonfinite;
+    uint64_t rays_live; /* closest-hit queries made with a non-zero throughput */
 } trace_counters;
 
 /* MonteCarloPathTracer::trace  src/tracers/mcpt.rs:20-43 over
@@ -600,6 +601,7 @@ static v3 trace(const rrt_scene_desc* sc, const ray_t* camera_ray, sampler_t* sa
     for (uint32_t depth = 0; depth < max_depth; ++depth) {
         hit_t hit;
         cnt->rays++;
+        if (beta.x != 0.0 || beta.y != 0.0 || beta.z != 0.0) cnt->rays_live++;
         if (!scene_intersect(sc, &ray, &hit)) break;
         const rrt_material* material = &sc->materials[hit.object_id];
         v3 emission = mat_emission(material);
@@ -632,7 +634,7 @@ typedef struct {
     size_t tiles_x, tile_count;
     size_t next_tile;
     pthread_mutex_t lock;
-    uint64_t samples, rays, bounces[5], nonfinite;
+    uint64_t samples, rays, rays_live, bounces[5], nonfinite;
     int failed;
 } render_job;
 
@@ -687,6 +689,7 @@ static void* render_worker(void* arg) {
     pthread_mutex_lock(&job->lock);
     job->samples += samples;
     job->rays += cnt.rays;
+    job->rays_live += cnt.rays_live;
     job->nonfinite += cnt.nonfinite;
     for (int i = 0; i < 5; ++i) job->bounces[i] += cnt.bounces[i];
     pthread_mutex_unlock(&job->lock);
@@ -726,6 +729,10 @@ int oracle_render_accumulate(const rrt_scene_desc* scene, const rrt_render_desc*
         memset(stats, 0, sizeof(*stats));
         stats->samples = job.samples;
         stats->rays = job.rays;
+        /* The reference keeps tracing a path whose throughput has become exactly zero (red wall then
+         * green wall) until Russian roulette or max_depth stops it.  `reserved` reports the queries
+         * made with non-zero throughput, for comparison with a backend that drops such paths. */
+        stats->reserved = (double)job.rays_live;
         stats->nonfinite = job.nonfinite;
         for (int i = 0; i < 5; ++i) stats->bounces[i] = job.bounces[i];
     }

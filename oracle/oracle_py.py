@@ -200,7 +200,9 @@ def render_accumulate(scene, render_desc, n_threads=0):
                                         C.byref(st), n_threads)
     if rc != 0:
         raise ValueError("oracle_render_accumulate rejected the configuration")
-    return rgb, st.as_dict()
+    out = st.as_dict()
+    out["rays_live"] = int(out.pop("reserved"))  # queries made with non-zero throughput
+    return rgb, out
 
 
 def postprocess(rgb_sum, spp_divisor, post_desc):

@@ -99,6 +99,7 @@ class Stats(C.Structure):
             "bounces": [int(b) for b in self.bounces],
             "nonfinite": int(self.nonfinite),
             "kernel_ms": float(self.kernel_ms),
+            "reserved": float(self.reserved),
         }
 
 
@@ -155,6 +156,14 @@ def load_library(path=None):
             f"HIP backend library not found at {p}; run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback)"
         )
+    # One process, one HIP runtime: PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 (same
+    # SONAMEs as /opt/rocm's).  If this library pulled in /opt/rocm's copies first, a later `import torch`
+    # would bring a second HSA runtime into the process and torch would see no GPU.  Importing torch first
+    # makes the dynamic linker resolve this library's libamdhip64.so.7 to the copy that is already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # a torch-free process simply uses the system ROCm runtime
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

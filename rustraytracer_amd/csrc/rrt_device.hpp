@@ -160,6 +160,19 @@ struct Sampler {
 
 RRT_DEV uint32_t next_bits(Sampler& s) { return mix32(s.key + (s.ctr++) * 0x9E3779B9U); }
 
+// (cell + jitter) / cells, kept inside [cell/cells, (cell+1)/cells): cell + jitter can
+// round up to cell + 1 in f32 when the jitter is within half an ulp of 1, which would
+// move the sample into the next stratum (or to 1.0, outside [0,1)).
+RRT_DEV float stratum_value(uint32_t cell, float jitter, uint32_t cells) {
+    const float inv = 1.0f / (float)cells;
+    float v = ((float)cell + jitter) * inv;
+    float hi = (float)(cell + 1u) * inv;
+    return v < hi ? v : __uint_as_float(__float_as_uint(hi) - 1u);
+}
+RRT_DEV double stratum_value(uint32_t cell, double jitter, uint32_t cells) {
+    return ((double)cell + jitter) / (double)cells;  // jitter has 32 bits: no round-up in f64
+}
+
 RRT_DEV void sampler_start(Sampler& s, const RenderParams& rp, uint32_t pixkey, uint32_t sample) {
     s.pixkey = pixkey;
     s.sample = sample;
@@ -179,7 +192,7 @@ RRT_DEV R get_1d(Sampler& s, const RenderParams& rp, bool needed) {
         uint32_t k = mix32(s.pixkey ^ ((2u * d + 1u) * 0x9E3779B9U));
         uint32_t stratum = permute(s.sample, rp.spp, rp.perm_mask, k);
         R j = Num<R>::uniform(next_bits(s));
-        return ((R)stratum + j) / (R)rp.spp;  // (i + xi) / spp, src/sampler.rs:108
+        return stratum_value(stratum, j, rp.spp);  // (i + xi) / spp, src/sampler.rs:108
     }
     if (!needed) return R(0);
     return Num<R>::uniform(next_bits(s));
@@ -201,8 +214,8 @@ RRT_DEV void get_2d(Sampler& s, const RenderParams& rp, R& a, R& b) {
             yc = cell / rp.x_strata;
             xc = cell - yc * rp.x_strata;
         }
-        a = ((R)xc + j0) / (R)rp.x_strata;
-        b = ((R)yc + j1) / (R)rp.y_strata;
+        a = stratum_value(xc, j0, rp.x_strata);
+        b = stratum_value(yc, j1, rp.y_strata);
         return;
     }
     a = j0;

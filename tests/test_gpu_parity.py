@@ -15,15 +15,23 @@ pytestmark = pytest.mark.gpu
 T_REL_TOL = 1e-5  # stated tolerance on hit distances
 
 
-def _compare(got, ref, id_slack, t_tol):
+def _compare(got, ref, id_slack, t_tol, tie_tol=0.0):
+    """ids must match, except on at most id_slack rays, and except where two DIFFERENT primitives lie at
+    the same distance within tie_tol (coincident surfaces, e.g. the bottom of a Cornell box on the floor:
+    which of two equal t wins depends on the last bit, and the reference's own answer there is an accident
+    of its rounding); distances of matching hits must agree within t_tol."""
     oid, pid, t = got
     bad = (oid != ref[0]) | (pid != ref[1])
-    assert bad.sum() <= id_slack, f"{int(bad.sum())} id mismatches"
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tie = bad & (ref[0] >= 0) & (oid >= 0) & (np.abs(t - ref[2]) <= tie_tol * np.abs(ref[2]))
+    hard = bad & ~tie
+    assert hard.sum() <= id_slack, f"{int(hard.sum())} id mismatches (+{int(tie.sum())} ties)"
     ok = ~bad & (ref[0] >= 0)
     rel = np.abs(t[ok] - ref[2][ok]) / ref[2][ok]
     assert rel.max() <= t_tol, rel.max()
     miss = ~bad & (ref[0] < 0)
     assert np.all(np.isinf(t[miss])) and np.all(pid[miss] == -1)
+    return int(tie.sum())
 
 
 @pytest.mark.parametrize("name", ["cornell_box", "smallpt"])
@@ -69,12 +77,17 @@ def test_secondary_rays(gpu, O, scenes, name):
     sc = api.Scene(flat)
     o, d = S.secondary_rays(flat, O, 100000, seed=17)
     ref = O.intersect(flat, o, d)
-    _compare(be.intersect(sc, o, d, precision=api.PRECISION_F64), ref, id_slack=0, t_tol=1e-9)
+    # directions cover the whole sphere, so some rays run INSIDE the Cornell boxes and leave through the
+    # box bottom, which lies in the floor plane: those are exact ties between two primitives
+    ties = _compare(be.intersect(sc, o, d, precision=api.PRECISION_F64), ref, id_slack=0, t_tol=1e-9, tie_tol=1e-12)
+    assert ties <= 0.005 * len(o)
     got = be.intersect(sc, o, d, precision=api.PRECISION_F32)
     bad = (got[0] != ref[0]) | (got[1] != ref[1])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        tie = bad & (np.abs(got[2] - ref[2]) <= 1e-5 * np.abs(ref[2]))
     # an f32 ray origin sits up to ~1e-7 * scale off the surface it starts on, so a few rays that leave a
     # surface at a grazing angle see that surface again beyond t_min; everything else must agree
-    assert bad.mean() <= 2e-3
+    assert (bad & ~tie).mean() <= 2e-3
 
 
 def test_tie_rule_on_device(gpu):

@@ -78,8 +78,13 @@ def test_analytic_materials(gpu, O, cfg):
     # glass ball: every sample is L (left the ball) or 0 (cut at max_depth)
     rgb, st = be.render_accumulate(api.Scene(S.glass_ball()), rc.render_desc())
     frac = (rgb / n) / np.array(S.L)
-    assert np.all(frac <= 1 + 1e-4) and frac.mean() > 0.97 and st["bounces"][4] > 0
+    # (a sample may keep the 1/eta^2 of its entry if f32 rounding makes it miss the far side of the ball
+    # at the silhouette: at most a few samples per image)
+    assert (frac > 1 + 1e-4).mean() < 2e-3 and frac.max() < 1.2
+    assert frac.mean() > 0.97 and abs(frac.mean() - 1) < 5e-3 and st["bounces"][4] > 0
     assert np.allclose(frac, frac[..., :1], atol=1e-5)
+    rgb64, _ = be.render_accumulate(api.Scene(S.glass_ball()), rc.render_desc(precision=api.PRECISION_F64))
+    assert np.all((rgb64 / n) / np.array(S.L) <= 1 + 1e-6)
 
 
 def test_max_depth_and_zero_depth(gpu, cfg):
@@ -114,30 +119,45 @@ def test_converged_image_rmse(gpu, O, cfg, scenes, name):
         assert st["nonfinite"] == 0
         for ref in (a, b):
             assert np.sqrt(np.mean((tm(x) - tm(ref)) ** 2)) <= 1.25 * base
-        assert abs(np.mean(tm(x)) - np.mean(tm(0.5 * (a + b)))) <= 0.01 * np.mean(tm(a))
+        # same spp on both sides: the tone curve is concave, so its mean depends on the noise level
+        assert abs(np.mean(tm(x)) - 0.5 * (np.mean(tm(a)) + np.mean(tm(b)))) <= 0.01 * np.mean(tm(a))
 
 
 @pytest.mark.parametrize("name", ["cornell_box", "smallpt"])
 def test_mean_radiance_and_path_statistics(gpu, O, cfg, scenes, name):
-    """A larger sample budget than the RMSE test: global mean radiance and rays per sample must agree
-    with the oracle to a fraction of a percent (catches small biases in sampling, RR and termination)."""
+    """A larger sample budget than the RMSE test: global mean radiance (linear, so unbiased at any spp)
+    and path statistics must agree with the oracle to within Monte-Carlo error.  Per-sample radiance has a
+    standard deviation of ~5 (tiny bright light), so the mean of the oracle's 4.2 M samples carries ~0.3 %
+    noise and the GPU's 16.8 M samples ~0.15 %: the 1.2 % gate is > 3 sigma yet catches a 2 % bias in
+    sampling, Russian roulette or termination."""
     api, be = gpu
     flat = scenes[name]
     sc = api.Scene(flat)
-    rc = cfg.stratified_config(64, 64, 16, 16, seed=3)
-    ref, rst = O.render_accumulate(flat, rc.render_desc(seed=4))
+    rc_o = cfg.stratified_config(64, 64, 32, 32, seed=4)
+    ref, rst = O.render_accumulate(flat, rc_o.render_desc())
+    rc = cfg.stratified_config(64, 64, 64, 64, seed=3)
     rgb, st = be.render_accumulate(sc, rc.render_desc())
-    assert st["samples"] == rst["samples"]
-    assert abs(st["rays"] / st["samples"] - rst["rays"] / rst["samples"]) < 0.01 * rst["rays"] / rst["samples"]
+    assert st["samples"] == 64 * 64 * 4096 and st["nonfinite"] == 0
+    # the backend drops a path once its throughput is exactly zero; the reference traces it on
+    live = rst["rays_live"] / rst["samples"]
+    assert abs(st["rays"] / st["samples"] - live) < 0.005 * live
+    assert rst["rays_live"] <= rst["rays"]
     for k in range(1, 5):
         if rst["bounces"][k] > 1000:
-            assert abs(st["bounces"][k] - rst["bounces"][k]) < 0.02 * rst["bounces"][k]
-    assert abs(tm(rgb / rc.spp).mean() - tm(ref / rc.spp).mean()) < 0.01 * tm(ref / rc.spp).mean()
+            assert abs(st["bounces"][k] / st["samples"] - rst["bounces"][k] / rst["samples"]) \
+                < 0.02 * rst["bounces"][k] / rst["samples"] + 2e-4  # (the oracle also scatters zero-throughput paths)
+    m_gpu = rgb.astype(np.float64).mean(axis=(0, 1)) / rc.spp
+    m_ref = ref.mean(axis=(0, 1)) / rc_o.spp
+    assert np.all(np.abs(m_gpu - m_ref) < 0.012 * m_ref), (m_gpu, m_ref)
     # Random sampler agrees with Stratified in the mean (after removing its (spp+1)/spp factor)
-    rr = cfg.random_config(64, 64, 256, seed=6)
+    rr = cfg.random_config(64, 64, 4096, seed=6)
     rgb_r, st_r = be.render_accumulate(sc, rr.render_desc())
-    assert st_r["samples"] == 64 * 64 * 257
-    assert abs(tm(rgb_r / 257).mean() - tm(ref / rc.spp).mean()) < 0.015 * tm(ref / rc.spp).mean()
+    assert st_r["samples"] == 64 * 64 * 4097
+    m_rand = rgb_r.astype(np.float64).mean(axis=(0, 1)) / 4097
+    assert np.all(np.abs(m_rand - m_ref) < 0.012 * m_ref), (m_rand, m_ref)
+    # and so does the f64 build of the kernels
+    rgb64, _ = be.render_accumulate(sc, cfg.stratified_config(64, 64, 32, 32, seed=8).render_desc(precision=api.PRECISION_F64))
+    assert np.all(np.abs(rgb64.astype(np.float64).mean(axis=(0, 1)) / 1024 - m_ref) < 0.015 * m_ref)
 
 
 def test_device_sampler_stratification(gpu, cfg):
