@@ -92,6 +92,18 @@ void prepare_prim(const rrt_prim& p, rrt::PrimRec<double>& rec, rrt::ShadeRec<do
     dual(e03, e01, n, v0, &rec.f[8]);
     if (quad) {
         D3 v3 = vl;
+        // v0 + v2 == v1 + v3 (to rounding): a parallelogram, whose second-corner coefficients are
+        // 1 - alpha and 1 - beta; its record stores alpha - 1/2 and beta - 1/2 and nothing more
+        D3 gap = (v0 + v2) - (v1 + v3);
+        double scale = std::sqrt(dot(e01, e01)) + std::sqrt(dot(e03, e03));
+        if (std::sqrt(dot(gap, gap)) <= 1e-12 * scale) {
+            rec.type = rrt::PRIM_PGRAM;
+            rec.f[7] -= 0.5;
+            rec.f[11] -= 0.5;
+            D3 sn0 = normalize(cross(v1 - v0, v2 - v0));
+            sh.nx = sn0.x; sh.ny = sn0.y; sh.nz = sn0.z;
+            return;
+        }
         D3 e23 = v3 - v2, e21 = v1 - v2;
         D3 n2 = cross(e23, e21);
         dual(e23, e21, n2, v2, &rec.f[12]);
@@ -209,6 +221,17 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view,
     if ((rc = upload(ds, m, &view.mats, stream)) != RRT_OK) return rc;
     view.n_prims = (int32_t)prims.size();
     view.n_objects = (int32_t)mats.size();
+    std::vector<int32_t> runs;  // maximal runs of equal record type, in scan order
+    for (size_t i = 0; i < prims.size(); ++i) {
+        if (i == 0 || prims[i].type != prims[i - 1].type) {
+            runs.push_back(prims[i].type);
+            runs.push_back((int32_t)i);
+            runs.push_back(0);
+        }
+        runs.back() += 1;
+    }
+    if ((rc = upload(ds, runs, &view.runs, stream)) != RRT_OK) return rc;
+    view.n_runs = (int32_t)(runs.size() / 3);
     HIP_TRY(hipStreamSynchronize(stream));  // the staging vectors die here
     return RRT_OK;
 }

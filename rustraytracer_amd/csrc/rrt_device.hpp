@@ -248,39 +248,53 @@ RRT_DEV V3<R> camera_dir(const SceneView<R>& sv, R s, R t) {
 // about half the arithmetic.  The second corner test of a quad is evaluated
 // at the same P (the reference intersects the second triangle's own plane,
 // which is the same plane for the planar quads its loader admits).
+//
+// The chain of early returns becomes ONE comparison: every condition is
+// written as "term >= 0" (x >= c <=> x - c >= 0 holds exactly in floating
+// point), the terms are folded with min / max (v_min3_f32 on gfx950) and the
+// primitive is accepted iff the fold is >= 0.  "A or B" is max(A, B).  min and
+// max drop a NaN operand, and the only source of NaN is n.d = 0, whose own
+// term |n.d| - 1e-6 is negative, so a NaN can never turn a reject into an
+// accept.  No branch, no exec-mask traffic: the scan is a straight run of FMAs.
 template <typename R>
-RRT_DEV bool prim_test(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
+RRT_DEV R min3(R a, R b, R c) {
+    return fmin(fmin(a, b), c);
+}
+
+// TYPE is a compile-time constant in the run loops of the linear scan (no per-primitive
+// dispatch) and a per-lane value in tree leaves.
+template <typename R, int TYPE>
+RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
     const R RRT_CONSTANT* f = p->f;
-    const int type = p->type;  // wave-uniform in the linear scan
-    if (type >= PRIM_TRIANGLE) {
+    if (TYPE >= PRIM_TRIANGLE) {
         R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
         R no = f[3] - (f[0] * o.x + f[1] * o.y + f[2] * o.z);
         R t = no * Num<R>::rcp(nd);
-        bool ok = !(Num<R>::abs(nd) < Num<R>::eps());
-        if (type == PRIM_QUAD)
-            ok = ok && !(t < Num<R>::tmin()) && !(t > best_t);
-        else
-            ok = ok && (t > Num<R>::tmin()) && (t < best_t);
-        if (__any(ok)) {
-            V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-            R a = f[4] * P.x + f[5] * P.y + f[6] * P.z + f[7];
-            R b = f[8] * P.x + f[9] * P.y + f[10] * P.z + f[11];
-            ok = ok && !(a < R(0)) && !(b < R(0));
-            if (type == PRIM_QUAD) {
-                R a2 = f[12] * P.x + f[13] * P.y + f[14] * P.z + f[15];
-                R b2 = f[16] * P.x + f[17] * P.y + f[18] * P.z + f[19];
-                R nd2 = f[20] * d.x + f[21] * d.y + f[22] * d.z;
-                bool second = (a + b) > R(1);
-                bool ok2 = !(Num<R>::abs(nd2) < Num<R>::eps()) && !(a2 < R(0)) && !(b2 < R(0));
-                ok = ok && (!second || ok2);
-            } else {
-                ok = ok && !(a > R(1)) && !((a + b) > R(1));
-            }
-        }
         t_out = t;
-        return ok;
+        V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+        R a = f[4] * P.x + f[5] * P.y + f[6] * P.z + f[7];
+        R b = f[8] * P.x + f[9] * P.y + f[10] * P.z + f[11];
+        R det_ok = Num<R>::abs(nd) - Num<R>::eps();
+        if (TYPE == PRIM_PGRAM) {
+            // parallelogram: alpha' = 1 - alpha and beta' = 1 - beta, so the two-triangle
+            // test is 0 <= alpha, beta <= 1; a and b arrive shifted by -1/2
+            R h = min3(R(0.5) - Num<R>::abs(a), R(0.5) - Num<R>::abs(b), det_ok);
+            return min3(h, t - Num<R>::tmin(), best_t - t) >= R(0);
+        }
+        if (TYPE == PRIM_QUAD) {
+            R a2 = f[12] * P.x + f[13] * P.y + f[14] * P.z + f[15];
+            R b2 = f[16] * P.x + f[17] * P.y + f[18] * P.z + f[19];
+            R nd2 = f[20] * d.x + f[21] * d.y + f[22] * d.z;
+            R second = min3(a2, b2, Num<R>::abs(nd2) - Num<R>::eps());  // the (v2, v3, v1) corner
+            R inside = fmax(R(1) - (a + b), second);                      // alpha + beta <= 1, or that corner
+            R h = min3(min3(a, b, inside), det_ok, t - Num<R>::tmin());
+            return fmin(h, best_t - t) >= R(0);
+        }
+        // triangle: u, v >= 0, u <= 1, u + v <= 1, and an OPEN t interval
+        R h = min3(min3(a, b, R(1) - a), R(1) - (a + b), det_ok);
+        return (h >= R(0)) && (fmin(t - Num<R>::tmin(), best_t - t) > R(0));
     }
-    if (type == PRIM_SPHERE) {  // src/shapes/sphere.rs:58-96
+    if (TYPE == PRIM_SPHERE) {  // src/shapes/sphere.rs:58-96
         V3<R> l = mk<R>(f[0] - o.x, f[1] - o.y, f[2] - o.z);
         R t_ca = dot(l, d);
         R d2;
@@ -293,22 +307,31 @@ RRT_DEV bool prim_test(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R bes
         } else {
             d2 = dot(l, l) - t_ca * t_ca;
         }
-        R r2 = f[4];
-        bool ok = !(d2 < R(0)) && !(d2 > r2);
-        R t_hc = Num<R>::sqrt(r2 - d2);
+        R x = f[4] - d2;                 // r^2 - d2 >= 0 <=> d2 <= r^2
+        R t_hc = Num<R>::sqrt(x);        // NaN when x < 0; the x term then rejects
         R t0 = t_ca - t_hc;
         R t1 = t_ca + t_hc;
         if (t0 < Num<R>::tmin()) t0 = t1;
-        ok = ok && !(t0 < Num<R>::tmin()) && !(t0 > best_t);
         t_out = t0;
-        return ok;
+        return min3(fmin(x, d2), t0 - Num<R>::tmin(), best_t - t0) >= R(0);
     }
     // plane, src/shapes/plane.rs:25-44
     R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
     R no = f[3] - (f[0] * o.x + f[1] * o.y + f[2] * o.z);
     R t = no * Num<R>::rcp(nd);
     t_out = t;
-    return !(Num<R>::abs(nd) < Num<R>::eps()) && !(t < Num<R>::tmin()) && !(t > best_t);
+    return min3(Num<R>::abs(nd) - Num<R>::eps(), t - Num<R>::tmin(), best_t - t) >= R(0);
+}
+
+template <typename R>
+RRT_DEV bool prim_test(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
+    switch (p->type) {
+    case PRIM_SPHERE: return prim_test_as<R, PRIM_SPHERE>(p, o, d, best_t, t_out);
+    case PRIM_PLANE: return prim_test_as<R, PRIM_PLANE>(p, o, d, best_t, t_out);
+    case PRIM_TRIANGLE: return prim_test_as<R, PRIM_TRIANGLE>(p, o, d, best_t, t_out);
+    case PRIM_QUAD: return prim_test_as<R, PRIM_QUAD>(p, o, d, best_t, t_out);
+    default: return prim_test_as<R, PRIM_PGRAM>(p, o, d, best_t, t_out);
+    }
 }
 
 struct HitCounters {
@@ -316,19 +339,36 @@ struct HitCounters {
     uint32_t node_tests;
 };
 
+template <typename R, int TYPE>
+RRT_DEV void scan_run(const PrimRec<R> RRT_CONSTANT* prims, int first, int count, V3<R> o, V3<R> d,
+                      R& best_t, int& best_g) {
+#pragma unroll 2
+    for (int k = 0; k < count; ++k) {
+        R t;
+        const bool ok = prim_test_as<R, TYPE>(prims + first + k, o, d, best_t, t);
+        best_t = ok ? t : best_t;
+        best_g = ok ? first + k : best_g;
+    }
+}
+
 // Scene::intersect (src/scene.rs:35-47) as a scan over the primitive table in
 // the reference's order with a shrinking t_max.  The table index is uniform
-// across the wave, so records arrive through scalar loads.
+// across the wave, so records arrive through scalar loads.  The table is cut
+// into runs of equal type (host side), each run is a tight loop of one test.
 template <typename R>
 RRT_DEV void scan_linear(const SceneView<R>& sv, V3<R> o, V3<R> d, R& best_t, int& best_g,
                          HitCounters& hc) {
-    const int n = sv.n_prims;
     const PrimRec<R> RRT_CONSTANT* prims = as_constant(sv.prims);
-    for (int i = 0; i < n; ++i) {
-        R t;
-        if (prim_test(prims + i, o, d, best_t, t)) {
-            best_t = t;
-            best_g = i;
+    const int32_t RRT_CONSTANT* runs = as_constant(sv.runs);
+    const int n_runs = sv.n_runs;
+    for (int r = 0; r < n_runs; ++r) {
+        const int type = runs[3 * r], first = runs[3 * r + 1], count = runs[3 * r + 2];
+        switch (type) {
+        case PRIM_SPHERE: scan_run<R, PRIM_SPHERE>(prims, first, count, o, d, best_t, best_g); break;
+        case PRIM_PLANE: scan_run<R, PRIM_PLANE>(prims, first, count, o, d, best_t, best_g); break;
+        case PRIM_TRIANGLE: scan_run<R, PRIM_TRIANGLE>(prims, first, count, o, d, best_t, best_g); break;
+        case PRIM_QUAD: scan_run<R, PRIM_QUAD>(prims, first, count, o, d, best_t, best_g); break;
+        default: scan_run<R, PRIM_PGRAM>(prims, first, count, o, d, best_t, best_g); break;
         }
     }
 }

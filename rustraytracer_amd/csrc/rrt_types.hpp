@@ -8,7 +8,10 @@
 
 namespace rrt {
 
-enum : int { PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_TRIANGLE = 2, PRIM_QUAD = 3 };
+enum : int {
+    PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_TRIANGLE = 2, PRIM_QUAD = 3,
+    PRIM_PGRAM = 4  // device-only: a quad whose corners form a parallelogram (PrimRec.type only)
+};
 enum : int { MAT_EMISSIVE = 0, MAT_LAMBERTIAN = 1, MAT_PHONG = 2, MAT_REFLECTOR = 3, MAT_DIELECTRIC = 4 };
 
 // Intersection record of one primitive: everything the per-ray test reads, in
@@ -20,7 +23,8 @@ enum : int { MAT_EMISSIVE = 0, MAT_LAMBERTIAN = 1, MAT_PHONG = 2, MAT_REFLECTOR 
 //     f[0..2] n = e01 x e03 (unnormalised)       f[3]  n . v0
 //     f[4..6] A,  f[7]  cA   alpha = A . P + cA   (coefficient of P - v0 on e01)
 //     f[8..10] B, f[11] cB   beta  = B . P + cB   (coefficient on e03)
-//     quad only, second corner v2:
+//     parallelogram (v0 + v2 == v1 + v3): cA and cB carry an extra -1/2, nothing else is read
+//     general quad only, second corner v2:
 //     f[12..14] A2, f[15] cA2   alpha' on e23 = v3 - v2
 //     f[16..18] B2, f[19] cB2   beta'  on e21 = v1 - v2
 //     f[20..22] n2 = e23 x e21
@@ -75,6 +79,9 @@ struct SceneView {
     const MatRec<R>* mats;     // n_objects
     int32_t n_prims;
     int32_t n_objects;
+    const int32_t* runs;       // n_runs x (type, first, count): maximal runs of equal PrimRec.type
+    int32_t n_runs;
+    int32_t pad0;
     // acceleration structure (n_bvh_prims == 0: linear scan over all prims)
     const BvhNode* nodes;
     const int32_t* bvh_prim;   // sorted slot -> scan-order primitive index
