@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -227,11 +228,25 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view,
             runs.push_back(prims[i].type);
             runs.push_back((int32_t)i);
             runs.push_back(0);
+            runs.push_back(0);
         }
-        runs.back() += 1;
+        runs[runs.size() - 2] += 1;
+    }
+    std::vector<rrt::PairRec<R>> pairs;  // parallelogram runs, two records side by side
+    for (size_t r = 0; r < runs.size(); r += 4) {
+        if (runs[r] != rrt::PRIM_PGRAM) continue;
+        runs[r + 3] = (int32_t)pairs.size();
+        for (int k = 0; k < runs[r + 2]; k += 2) {
+            rrt::PairRec<R> pr;
+            std::memset(&pr, 0, sizeof(pr));
+            for (int h = 0; h < 2 && k + h < runs[r + 2]; ++h)
+                for (int j = 0; j < 12; ++j) pr.g[j][h] = p[(size_t)runs[r + 1] + k + h].f[j];
+            pairs.push_back(pr);
+        }
     }
     if ((rc = upload(ds, runs, &view.runs, stream)) != RRT_OK) return rc;
-    view.n_runs = (int32_t)(runs.size() / 3);
+    if ((rc = upload(ds, pairs, &view.pairs, stream)) != RRT_OK) return rc;
+    view.n_runs = (int32_t)(runs.size() / 4);
     HIP_TRY(hipStreamSynchronize(stream));  // the staging vectors die here
     return RRT_OK;
 }
@@ -380,11 +395,18 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
     rp.n_samples = (uint32_t)(desc->sample_end - desc->sample_begin);
     // samples per work item: enough items to balance the tail, few enough to keep
     // the per-item atomics and the 32-bit item index negligible / valid
-    uint32_t chunk = rp.n_samples < 128 ? rp.n_samples : 128;
+    uint32_t target = 128;
+    if (const char* e = getenv("RRT_DEBUG_CHUNK")) target = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 128;  // experiments
+    uint32_t chunk = rp.n_samples < target ? rp.n_samples : target;
     while ((uint64_t)((rp.n_samples + chunk - 1) / chunk) * n_pixels >= (1ull << 31)) chunk *= 2;
     rp.chunk = chunk;
     rp.n_chunks = (rp.n_samples + chunk - 1) / chunk;
     rp.n_items = (uint64_t)rp.n_chunks * n_pixels;
+    rp.inv_width = 1.0f / (float)rp.width;
+    rp.inv_height = 1.0f / (float)rp.height;
+    rp.inv_spp = 1.0f / (float)rp.spp;
+    rp.inv_x_strata = 1.0f / (float)rp.x_strata;
+    rp.inv_y_strata = 1.0f / (float)rp.y_strata;
     rp.seed_lo = (uint32_t)desc->seed;
     rp.seed_hi = (uint32_t)(desc->seed >> 32);
     return rp;

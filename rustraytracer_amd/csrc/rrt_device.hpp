@@ -102,6 +102,9 @@ RRT_DEV V3<R> normalize(V3<R> a) {
 // Counter-based: every number is a hash of (seed, pixel, sample, draw index);
 // there is no generator state to carry in a queue or to advance in order.
 RRT_DEV uint32_t mix32(uint32_t x) {
+#ifdef RRT_EXP_CHEAPHASH
+    return x ^ (x >> 7) ^ (x << 11);
+#endif
     x ^= x >> 16;
     x *= 0x7feb352dU;
     x ^= x >> 15;
@@ -114,7 +117,7 @@ RRT_DEV uint32_t pixel_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t pixel) {
     return mix32(seed_lo ^ mix32(pixel * 0x9E3779B1U + (mix32(seed_hi) | 1U)));
 }
 RRT_DEV uint32_t sample_key(uint32_t pixkey, uint32_t sample) {
-    return mix32(pixkey + mix32(sample ^ 0x85EBCA6BU) * 0xC2B2AE35U);
+    return mix32(pixkey + sample * 0x9E3779B9U);
 }
 
 // Kensler's hash-based permutation of {0..l-1} ("Correlated Multi-Jittered
@@ -122,6 +125,9 @@ RRT_DEV uint32_t sample_key(uint32_t pixkey, uint32_t sample) {
 // index at a time, which replaces the reference's per-pixel shuffled tables
 // (src/sampler.rs:105-125).  w = next_pow2(l) - 1.
 RRT_DEV uint32_t permute(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
+#ifdef RRT_EXP_CHEAPHASH
+    return (i ^ p) & w;
+#endif
     do {
         i ^= p;
         i *= 0xe170893dU;
@@ -162,14 +168,13 @@ RRT_DEV uint32_t next_bits(Sampler& s) { return mix32(s.key + (s.ctr++) * 0x9E37
 
 // (cell + jitter) / cells, kept inside [cell/cells, (cell+1)/cells): cell + jitter can
 // round up to cell + 1 in f32 when the jitter is within half an ulp of 1, which would
-// move the sample into the next stratum (or to 1.0, outside [0,1)).
-RRT_DEV float stratum_value(uint32_t cell, float jitter, uint32_t cells) {
-    const float inv = 1.0f / (float)cells;
+// move the sample into the next stratum (or to 1.0, outside [0,1)).  inv = 1 / cells.
+RRT_DEV float stratum_value(uint32_t cell, float jitter, uint32_t cells, float inv) {
     float v = ((float)cell + jitter) * inv;
     float hi = (float)(cell + 1u) * inv;
     return v < hi ? v : __uint_as_float(__float_as_uint(hi) - 1u);
 }
-RRT_DEV double stratum_value(uint32_t cell, double jitter, uint32_t cells) {
+RRT_DEV double stratum_value(uint32_t cell, double jitter, uint32_t cells, float) {
     return ((double)cell + jitter) / (double)cells;  // jitter has 32 bits: no round-up in f64
 }
 
@@ -192,7 +197,7 @@ RRT_DEV R get_1d(Sampler& s, const RenderParams& rp, bool needed) {
         uint32_t k = mix32(s.pixkey ^ ((2u * d + 1u) * 0x9E3779B9U));
         uint32_t stratum = permute(s.sample, rp.spp, rp.perm_mask, k);
         R j = Num<R>::uniform(next_bits(s));
-        return stratum_value(stratum, j, rp.spp);  // (i + xi) / spp, src/sampler.rs:108
+        return stratum_value(stratum, j, rp.spp, rp.inv_spp);  // (i + xi) / spp, src/sampler.rs:108
     }
     if (!needed) return R(0);
     return Num<R>::uniform(next_bits(s));
@@ -214,8 +219,8 @@ RRT_DEV void get_2d(Sampler& s, const RenderParams& rp, R& a, R& b) {
             yc = cell / rp.x_strata;
             xc = cell - yc * rp.x_strata;
         }
-        a = stratum_value(xc, j0, rp.x_strata);
-        b = stratum_value(yc, j1, rp.y_strata);
+        a = stratum_value(xc, j0, rp.x_strata, rp.inv_x_strata);
+        b = stratum_value(yc, j1, rp.y_strata, rp.inv_y_strata);
         return;
     }
     a = j0;
@@ -351,6 +356,39 @@ RRT_DEV void scan_run(const PrimRec<R> RRT_CONSTANT* prims, int first, int count
     }
 }
 
+// Two parallelograms per step with packed FP32 arithmetic: component 0 of every R2 belongs
+// to the first record of the pair, component 1 to the second.  The dot products, t, the hit
+// point and both coefficients are packed (one issue slot for two primitives); reciprocal,
+// |x|, min3 and the selects have no packed form.  The second record is judged against the
+// closest hit as updated by the first, exactly as in a sequential scan.
+template <typename R>
+RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int count, V3<R> o, V3<R> d,
+                            R& best_t, int& best_g) {
+    typedef R R2 __attribute__((ext_vector_type(2)));
+    const int n_pairs = (count + 1) >> 1;
+    for (int k = 0; k < n_pairs; ++k) {
+        const R2 RRT_CONSTANT* f = reinterpret_cast<const R2 RRT_CONSTANT*>(pairs[k].g);
+        R2 nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
+        R2 no = ((f[3] - f[0] * o.x) - f[1] * o.y) - f[2] * o.z;
+        R2 rc;
+        rc.x = Num<R>::rcp(nd.x);
+        rc.y = Num<R>::rcp(nd.y);
+        R2 t = no * rc;
+        R2 px = o.x + t * d.x, py = o.y + t * d.y, pz = o.z + t * d.z;
+        R2 a = f[4] * px + (f[5] * py + (f[6] * pz + f[7]));
+        R2 b = f[8] * px + (f[9] * py + (f[10] * pz + f[11]));
+        R2 tm = t - Num<R>::tmin();
+        R h0 = min3(R(0.5) - Num<R>::abs(a.x), R(0.5) - Num<R>::abs(b.x), Num<R>::abs(nd.x) - Num<R>::eps());
+        const bool ok0 = min3(h0, tm.x, best_t - t.x) >= R(0);
+        best_t = ok0 ? t.x : best_t;
+        best_g = ok0 ? first + 2 * k : best_g;
+        R h1 = min3(R(0.5) - Num<R>::abs(a.y), R(0.5) - Num<R>::abs(b.y), Num<R>::abs(nd.y) - Num<R>::eps());
+        const bool ok1 = min3(h1, tm.y, best_t - t.y) >= R(0);
+        best_t = ok1 ? t.y : best_t;
+        best_g = ok1 ? first + 2 * k + 1 : best_g;
+    }
+}
+
 // Scene::intersect (src/scene.rs:35-47) as a scan over the primitive table in
 // the reference's order with a shrinking t_max.  The table index is uniform
 // across the wave, so records arrive through scalar loads.  The table is cut
@@ -362,13 +400,13 @@ RRT_DEV void scan_linear(const SceneView<R>& sv, V3<R> o, V3<R> d, R& best_t, in
     const int32_t RRT_CONSTANT* runs = as_constant(sv.runs);
     const int n_runs = sv.n_runs;
     for (int r = 0; r < n_runs; ++r) {
-        const int type = runs[3 * r], first = runs[3 * r + 1], count = runs[3 * r + 2];
+        const int type = runs[4 * r], first = runs[4 * r + 1], count = runs[4 * r + 2];
         switch (type) {
         case PRIM_SPHERE: scan_run<R, PRIM_SPHERE>(prims, first, count, o, d, best_t, best_g); break;
         case PRIM_PLANE: scan_run<R, PRIM_PLANE>(prims, first, count, o, d, best_t, best_g); break;
         case PRIM_TRIANGLE: scan_run<R, PRIM_TRIANGLE>(prims, first, count, o, d, best_t, best_g); break;
         case PRIM_QUAD: scan_run<R, PRIM_QUAD>(prims, first, count, o, d, best_t, best_g); break;
-        default: scan_run<R, PRIM_PGRAM>(prims, first, count, o, d, best_t, best_g); break;
+        default: scan_run_pairs<R>(as_constant(sv.pairs) + runs[4 * r + 3], first, count, o, d, best_t, best_g); break;
         }
     }
 }

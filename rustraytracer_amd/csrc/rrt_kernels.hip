@@ -10,6 +10,8 @@
 //   postprocess_kernel mean -> reinhard -> gamma -> white balance -> u8
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rrt_launch.hpp"
 #include "rrt_shade.hpp"
 
@@ -58,60 +60,116 @@ intersect_kernel(SceneView<R> sv, size_t n, const double* __restrict__ a, const 
 }
 
 // ------------------------------------------------------------------ fused renderer
-// Work item = (pixel, chunk of consecutive sample indices).  Items are handed
-// out through one global counter; the lanes of a wave that need an item at the
-// same time share one atomic (ballot + popcount + lane rank).
+// One path per lane, kept in registers for all of its bounces.  Work item =
+// (pixel, chunk of consecutive sample indices); items are handed out through one
+// global counter, and the lanes of a wave that need an item at the same time
+// share one atomic (ballot + popcount + lane rank).
+//
+// One trip of the loop is, for every lane:
+//   E  closest hit of the lane's current ray            (src/scene.rs:35-47)
+//   F  hit processing: emission, Russian roulette        (src/tracers/utils.rs:41-64)
+//   A  a lane whose sample just ended closes its item / takes a new one
+//   B  ... and starts its next camera sample             (src/renderer.rs:118-119)
+//   C  ONE 2D sampler draw for all lanes: the pixel jitter of a lane that starts
+//      a sample, the lobe sample of a lane that scatters
+//   D  the new ray: Camera::create_ray or Material::scatter
+// so a lane whose path ended in F has a fresh camera ray by the end of the same
+// trip and (almost) all 64 lanes are live in every scan; the expensive sampler
+// code (hash, stratum permutation) runs once per trip at full occupancy instead
+// of once for ray generation and once for scattering.
 template <typename R, bool BVH>
 __global__ void __launch_bounds__(256)
 render_fused(SceneView<R> sv, RenderParams rp) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_pixels = rp.width * rp.height;
 
-    bool have_item = false, alive = false, exhausted = false;
-    uint32_t pixel = 0, pixkey = 0, s_cur = 0, s_end = 0;
-    V3<R> acc = mk<R>(0, 0, 0);      // radiance sum of the current item
-    V3<R> radiance = mk<R>(0, 0, 0); // radiance of the current sample
+    constexpr uint32_t POOL_ITEMS = 64;  // items per refill of the wave's pool
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform
+
+    bool have_item = false, have_ray = false, exhausted = false;
+    uint32_t pixel = 0, pixkey = 0, s_next = 0, s_end = 0;
+    R px_c = 0, py_c = 0;        // pixel coordinates + 0.5 of the current item
+    V3<R> acc = mk<R>(0, 0, 0);  // radiance sum of the current item
     Path<R> path;
     path.o = path.d = path.beta = mk<R>(0, 0, 0);
     path.depth = 0;
     path.smp = Sampler{0, 0, 0, 0, 4};
 
-    // wave-uniform event counters (live in SGPRs)
+    // wave-uniform event counters: bumped by ballots taken outside the divergent
+    // regions, so they stay in scalar registers
     uint32_t c_rays = 0, c_nonfinite = 0, c_samples = 0;
     HitCounters hc{0, 0};
     BounceCounters bc{{0, 0, 0, 0, 0}};
 
     for (;;) {
-        // -- a finished path: close the sample, and the item after its last sample
-        if (!alive && have_item && s_cur == s_end) {
+        // -- E + F
+        c_rays += (uint32_t)__popcll(__ballot(have_ray));
+        int mode = MODE_NEW, counted = -1;
+        bool bad = false;
+        V3<R> n = mk<R>(0, 0, 0);
+        MatRec<R> m;
+        m.r = m.g = m.b = m.param = R(0);
+        m.type = 0;
+        if (have_ray) {
+            R t;
+#ifdef RRT_EXP_NOSCAN
+            int g = (int)(path.smp.key % (uint32_t)sv.n_prims);
+            t = R(0.3);
+#else
+            int g = closest_hit<R, BVH>(sv, path.o, path.d, t, hc);
+#endif
+#ifdef RRT_EXP_NOSHADE
+            acc.x += t; acc.y += (R)g;
+#else
+            if (g >= 0) mode = process_hit<R>(sv, rp, path, g, t, acc, n, m, bad, counted);
+#endif
+        }
+        c_nonfinite += (uint32_t)__popcll(__ballot(bad));
+#pragma unroll
+        for (int k = 1; k < 5; ++k) bc.bounce[k] += (uint32_t)__popcll(__ballot(counted == k));
+
+        // -- A: the sample is over: close the item after its last sample, take the next one
+        const bool fresh = mode == MODE_NEW && !exhausted;
+        if (fresh && have_item && s_next == s_end) {
             atomicAdd(&rp.accum[3 * (size_t)pixel + 0], (float)acc.x);
             atomicAdd(&rp.accum[3 * (size_t)pixel + 1], (float)acc.y);
             atomicAdd(&rp.accum[3 * (size_t)pixel + 2], (float)acc.z);
             have_item = false;
         }
-        const bool need = !alive && !have_item && !exhausted;
+        const bool need = fresh && !have_item;
         const unsigned long long need_mask = __ballot(need);
         if (need_mask) {
+            // Items come from a wave-private pool [pool_next, pool_end) held in scalar registers; one
+            // global atomic refills it with POOL_ITEMS consecutive items.  (One atomic per requesting
+            // wave and item, on a single counter word, saturates at well under 100 M/s chip-wide and
+            // was the bottleneck of the whole kernel.)
             const uint32_t cnt = (uint32_t)__popcll(need_mask);
-            const int leader = __ffsll((long long)need_mask) - 1;
-            unsigned long long base = 0;
-            if ((int)lane == leader) base = atomicAdd(rp.work_counter, (unsigned long long)cnt);
-            uint32_t blo = __builtin_amdgcn_readlane((uint32_t)base, leader);
-            uint32_t bhi = __builtin_amdgcn_readlane((uint32_t)(base >> 32), leader);
-            base = ((unsigned long long)bhi << 32) | blo;
+            const uint32_t avail = pool_end - pool_next;
+            uint32_t fresh_base = 0;
+            if (cnt > avail) {
+                const int leader = __ffsll((long long)need_mask) - 1;
+                unsigned long long got = 0;
+                if ((int)lane == leader) got = atomicAdd(rp.work_counter, (unsigned long long)POOL_ITEMS);
+                uint32_t lo = __builtin_amdgcn_readlane((uint32_t)got, leader);
+                uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(got >> 32), leader);
+                // the counter only ever exceeds n_items (< 2^31) by one pool per wave: no wrap
+                fresh_base = hi ? 0xfffffff0u : lo;
+            }
             if (need) {
                 uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
-                unsigned long long w = base + rank;
-                if (w < rp.n_items) {
-                    uint32_t w32 = (uint32_t)w;  // n_items < 2^32 (checked by the launcher)
+                uint32_t w32 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
+                if ((unsigned long long)w32 < rp.n_items) {
                     uint32_t chunk = w32 / n_pixels;
                     pixel = w32 - chunk * n_pixels;
                     pixkey = pixel_key(rp.seed_lo, rp.seed_hi, pixel);
+                    uint32_t py = pixel / rp.width;
+                    px_c = (R)(pixel - py * rp.width) + R(0.5);
+                    py_c = (R)py + R(0.5);
                     uint32_t first = chunk * rp.chunk;
                     uint32_t last = first + rp.chunk;
                     if (last > rp.n_samples) last = rp.n_samples;
-                    s_cur = rp.sample_begin + first;
+                    s_next = rp.sample_begin + first;
                     s_end = rp.sample_begin + last;
                     acc = mk<R>(0, 0, 0);
                     have_item = true;
@@ -119,49 +177,48 @@ render_fused(SceneView<R> sv, RenderParams rp) {
                     exhausted = true;
                 }
             }
+            if (cnt > avail) {
+                pool_next = fresh_base + (cnt - avail);
+                pool_end = fresh_base + POOL_ITEMS;
+            } else {
+                pool_next += cnt;
+            }
         }
         if (__ballot(!exhausted) == 0ull) break;
 
-        // -- raygen: the head of the sample loop, src/renderer.rs:118-122
-        // (event counters are wave-uniform: they are bumped by ballots taken
-        // outside the divergent regions, so they stay in scalar registers)
-        const bool gen = !alive && have_item;
-        c_samples += (uint32_t)__popcll(__ballot(gen));
-        if (gen) {
-            sampler_start(path.smp, rp, pixkey, s_cur);
-            s_cur += 1;
-            R u_off, v_off;
-            get_2d<R>(path.smp, rp, u_off, v_off);
-            uint32_t py = pixel / rp.width;
-            uint32_t px = pixel - py * rp.width;
-            R u = ((R)px + u_off + R(0.5)) / (R)rp.width;
-            R v = R(1) - ((R)py + v_off + R(0.5)) / (R)rp.height;
+        // -- B: the head of the sample loop, src/renderer.rs:118-119
+        const bool start = fresh && have_item;
+        c_samples += (uint32_t)__popcll(__ballot(start));
+        if (start) {
+            sampler_start(path.smp, rp, pixkey, s_next);
+            s_next += 1;
+        }
+
+        // -- C: one 2D draw for every lane that needs one
+        R u2 = R(0), v2 = R(0);
+        if (start || mode == MAT_LAMBERTIAN || mode == MAT_PHONG) get_2d<R>(path.smp, rp, u2, v2);
+
+        // -- D: the next ray
+        have_ray = false;
+        if (start) {
+            // u = (x + u_off + 0.5) / W, v = 1 - (y + v_off + 0.5) / H (src/renderer.rs:120-121);
+            // the f32 kernels multiply by a reciprocal prepared on the host
+            R u, v;
+            if (sizeof(R) == 4) {
+                u = (px_c + u2) * (R)rp.inv_width;
+                v = R(1) - (py_c + v2) * (R)rp.inv_height;
+            } else {
+                u = (px_c + u2) / (R)rp.width;
+                v = R(1) - (py_c + v2) / (R)rp.height;
+            }
             path.o = mk<R>(sv.cam_o[0], sv.cam_o[1], sv.cam_o[2]);
             path.d = camera_dir<R>(sv, u, v);
             path.beta = mk<R>(1, 1, 1);
             path.depth = 0;
-            radiance = mk<R>(0, 0, 0);
-            alive = true;
+            have_ray = true;
+        } else if (mode != MODE_NEW) {
+            have_ray = scatter<R>(rp, path, mode, n, m, u2, v2);
         }
-
-        // -- one bounce: closest hit + shading, src/tracers/utils.rs:35-88
-        c_rays += (uint32_t)__popcll(__ballot(alive));
-        int scattered = -1;  // material type whose scatter was evaluated this iteration
-        bool ended_bad = false;
-        if (alive) {
-            R t;
-            int g = closest_hit<R, BVH>(sv, path.o, path.d, t, hc);
-            bool cont = false;
-            if (g >= 0) cont = shade_bounce<R>(sv, rp, path, g, t, radiance, scattered);
-            if (!cont) {
-                alive = false;
-                ended_bad = !(isfinite(radiance.x) && isfinite(radiance.y) && isfinite(radiance.z));
-                acc = acc + radiance;
-            }
-        }
-        c_nonfinite += (uint32_t)__popcll(__ballot(ended_bad));
-#pragma unroll
-        for (int k = 1; k < 5; ++k) bc.bounce[k] += (uint32_t)__popcll(__ballot(scattered == k));
     }
     if (!BVH) hc.prim_tests = c_rays * (uint32_t)sv.n_prims;  // a linear scan tests every primitive
 
@@ -234,7 +291,9 @@ hipError_t launch_intersect(const SceneView<double>& sv, bool primary, size_t n,
 template <typename R>
 static hipError_t launch_render_fused_t(const SceneView<R>& sv, const RenderParams& rp, int n_blocks,
                                         hipStream_t stream) {
-    hipLaunchKernelGGL((render_fused<R, false>), dim3(n_blocks), dim3(256), 0, stream, sv, rp);
+    // RRT_DEBUG_LDS_BYTES: occupancy experiments only (unused dynamic LDS caps the blocks per CU)
+    static const size_t lds = [] { const char* e = getenv("RRT_DEBUG_LDS_BYTES"); return e ? (size_t)atol(e) : (size_t)0; }();
+    hipLaunchKernelGGL((render_fused<R, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
     return hipGetLastError();
 }
 hipError_t launch_render_fused(const SceneView<float>& sv, const RenderParams& rp, int n_blocks, hipStream_t s) {

@@ -46,28 +46,29 @@ struct BounceCounters {
     uint32_t bounce[5];
 };
 
-// One iteration of the loop body of generate_camera_vertices AFTER the
-// closest-hit query (src/tracers/utils.rs:41-87) for a path that hit primitive
-// g at distance t.  Adds emitted radiance to `radiance` when the vertex is an
-// emitter (connect with s = 0, src/tracers/utils.rs:115-121).  Returns true if
-// the path continues with the new ray in `p`; `scattered` receives the type of
-// the material whose scatter was evaluated (left alone if none was).
+// What is left to do for a path after its closest-hit query.
+//   MODE_NEW: the sample is over (miss, emitter, Russian roulette, depth limit);
+//   otherwise the material type whose scatter gives the next ray.
+enum : int { MODE_NEW = 0 };
+
+// The part of the loop body of generate_camera_vertices between the closest-hit
+// query and the scatter call (src/tracers/utils.rs:41-64) for a path that hit
+// primitive g at distance t: emitted radiance goes to `acc` (connect with s = 0,
+// utils.rs:115-121), Russian roulette may end the path, and otherwise the hit
+// point becomes the new origin and the surface (normal, material) is handed to
+// the scatter step.  Returns the mode for that step; `counted` receives the
+// material type whose scatter the reference would now evaluate (-1 if none).
 //
-// The throughput factor cos * bxdf / pdf (utils.rs:76-82) is applied in its
-// reduced form, which is the same number wherever pdf > 1e-6:
-//   Lambertian      (|c| albedo/pi) / (c/pi)                 = albedo
-//   PhongSpecular   |d.n| spec (s+2)/(2pi) c^s / (c^s (s+1)/(2pi)) = spec |d.n| (s+2)/(s+1)
-//   IdealReflector  c (1/c) / 1                              = 1   (0 if d.n <= 1e-6)
-//   IdealDielectric reflect: c (F/c) / F = 1; refract: c ((1-F)/(c eta^2)) / (1-F) = 1/eta^2
-//                   (0 if |d.n| < 1e-6)
-// A path whose throughput became exactly zero is dropped: it can only add zero.
+// A path at its last permitted vertex (depth + 1 == max_depth) ends here: the
+// reference still scatters it (utils.rs:66-87) and then leaves its loop, so the
+// new ray is never traced and nothing it computed can reach the image.
 template <typename R>
-RRT_DEV bool shade_bounce(const SceneView<R>& sv, const RenderParams& rp, Path<R>& p, int g, R t,
-                          V3<R>& radiance, int& scattered) {
+RRT_DEV int process_hit(const SceneView<R>& sv, const RenderParams& rp, Path<R>& p, int g, R t, V3<R>& acc,
+                        V3<R>& n, MatRec<R>& m, bool& bad, int& counted) {
     const ShadeRec<R> sh = sv.shade[g];
-    const MatRec<R> m = sv.mats[sh.object_id];
+    m = sv.mats[sh.object_id];
     V3<R> P = mk<R>(p.o.x + t * p.d.x, p.o.y + t * p.d.y, p.o.z + t * p.d.z);
-    V3<R> n = mk<R>(sh.nx, sh.ny, sh.nz);
+    n = mk<R>(sh.nx, sh.ny, sh.nz);
     if (sh.type == PRIM_SPHERE) {  // (point - center) / radius, src/shapes/sphere.rs:87
         R inv_r = Num<R>::rcp(sh.w);
         n = mk<R>((P.x - sh.nx) * inv_r, (P.y - sh.ny) * inv_r, (P.z - sh.nz) * inv_r);
@@ -75,25 +76,42 @@ RRT_DEV bool shade_bounce(const SceneView<R>& sv, const RenderParams& rp, Path<R
     if (m.type == MAT_EMISSIVE) {
         // an Emissive surface ends the path either way: as an emitter
         // (utils.rs:52-54) or because its scatter returns None (material.rs:44-46)
-        radiance.x += p.beta.x * m.r;
-        radiance.y += p.beta.y * m.g;
-        radiance.z += p.beta.z * m.b;
-        return false;
+        V3<R> c = mk<R>(p.beta.x * m.r, p.beta.y * m.g, p.beta.z * m.b);
+        bad = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
+        acc = acc + c;
+        return MODE_NEW;
     }
     // Russian roulette (utils.rs:56-64): one 1D draw per bounce, used or not
     const bool rr = p.depth > rp.min_depth;
     R xi = get_1d<R>(p.smp, rp, rr);
     if (rr) {
         R q = fmin(fmax(fmax(p.beta.x, p.beta.y), p.beta.z), R(1));
-        if (xi > q) return false;
-        R inv_q = R(1) / q;
-        p.beta = p.beta * inv_q;
+        if (xi > q) return MODE_NEW;
+        p.beta = p.beta * Num<R>::rcp(q);
     }
+    counted = m.type;
+    if (p.depth + 1u >= rp.max_depth) return MODE_NEW;  // `for depth in 0..max_depth`
+    p.o = P;
+    return m.type;
+}
+
+// Material::scatter + bxdf for one path (src/material.rs:67-284) given the
+// surface found by process_hit and, for the two lobe samplers, the 2D sample
+// (u, v) drawn for it.  On success the path carries the new direction and the
+// updated throughput and the function returns true.
+//
+// The throughput factor cos * bxdf / pdf (src/tracers/utils.rs:76-82) is applied
+// in its reduced form, which is the same number wherever pdf > 1e-6:
+//   Lambertian      (|c| albedo/pi) / (c/pi)                 = albedo
+//   PhongSpecular   |d.n| spec (s+2)/(2pi) c^s / (c^s (s+1)/(2pi)) = spec |d.n| (s+2)/(s+1)
+//   IdealReflector  c (1/c) / 1                              = 1   (0 if d.n <= 1e-6)
+//   IdealDielectric reflect: c (F/c) / F = 1; refract: c ((1-F)/(c eta^2)) / (1-F) = 1/eta^2
+//                   (0 if |d.n| < 1e-6)
+// A path whose throughput became exactly zero is dropped: it can only add zero.
+template <typename R>
+RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u, R v) {
     V3<R> dir;
-    if (m.type == MAT_LAMBERTIAN) {  // src/material.rs:67-91
-        scattered = MAT_LAMBERTIAN;
-        R u, v;
-        get_2d<R>(p.smp, rp, u, v);
+    if (mode == MAT_LAMBERTIAN) {  // src/material.rs:67-91
         R cos_t = Num<R>::sqrt(R(1) - u);  // theta = acos(sqrt(1 - u))
         R sin_t = Num<R>::sqrt(u);
         R sp, cp;
@@ -102,11 +120,8 @@ RRT_DEV bool shade_bounce(const SceneView<R>& sv, const RenderParams& rp, Path<R
         R pdf = dot(dir, n) * Num<R>::inv_pi();
         if (pdf <= Num<R>::eps()) return false;
         p.beta = mk<R>(p.beta.x * m.r, p.beta.y * m.g, p.beta.z * m.b);
-    } else if (m.type == MAT_PHONG) {  // src/material.rs:104-142
-        scattered = MAT_PHONG;
+    } else if (mode == MAT_PHONG) {  // src/material.rs:104-142
         V3<R> refl = reflect(p.d, n);
-        R u, v;
-        get_2d<R>(p.smp, rp, u, v);
         R s = m.param;
         R cos_t = Num<R>::pow(u, R(1) / (s + R(1)));
         R sin_t = Num<R>::sqrt(fmax(R(1) - cos_t * cos_t, R(0)));
@@ -118,12 +133,10 @@ RRT_DEV bool shade_bounce(const SceneView<R>& sv, const RenderParams& rp, Path<R
         if (!(pdf > Num<R>::eps())) return false;
         R w = Num<R>::abs(dot(dir, n)) * (s + R(2)) / (s + R(1));
         p.beta = mk<R>(p.beta.x * m.r * w, p.beta.y * m.g * w, p.beta.z * m.b * w);
-    } else if (m.type == MAT_REFLECTOR) {  // src/material.rs:156-181
-        scattered = MAT_REFLECTOR;
+    } else if (mode == MAT_REFLECTOR) {  // src/material.rs:156-181
         dir = reflect(p.d, n);
         if (!(dot(dir, n) > Num<R>::eps())) return false;
     } else {  // IdealDielectric, src/material.rs:193-284
-        scattered = MAT_DIELECTRIC;
         R dn = dot(p.d, n);
         const bool inside = dn > R(0);
         V3<R> on = inside ? mk<R>(-n.x, -n.y, -n.z) : n;
@@ -151,10 +164,8 @@ RRT_DEV bool shade_bounce(const SceneView<R>& sv, const RenderParams& rp, Path<R
         if (Num<R>::abs(dot(dir, n)) < Num<R>::eps()) return false;
         p.beta = p.beta * w;
     }
-    p.o = P;
     p.d = dir;
     p.depth += 1;
-    if (p.depth >= rp.max_depth) return false;  // `for depth in 0..max_depth`
     return !(p.beta.x == R(0) && p.beta.y == R(0) && p.beta.z == R(0));
 }
 

@@ -36,6 +36,15 @@ struct PrimRec {
     int32_t type;
 };
 
+// Two parallelograms of one run side by side: g[k] = (f[k] of the first, f[k] of the second),
+// k = 0..11.  A wave-uniform pair lands in 24 SGPRs as 12 aligned pairs, which is the operand
+// shape of the packed FP32 instructions (v_pk_fma_f32 & co. do two FMAs per lane per issue
+// slot).  An odd run is padded with an all-zero record, which every ray rejects (n . d = 0).
+template <typename R>
+struct PairRec {
+    R g[12][2];
+};
+
 // What shading needs from the primitive that was hit (one gather per bounce).
 //   triangle / quad / plane: n = the unit normal the reference reports
 //   sphere: n = centre, w = radius (normal = (P - centre) / radius)
@@ -79,7 +88,8 @@ struct SceneView {
     const MatRec<R>* mats;     // n_objects
     int32_t n_prims;
     int32_t n_objects;
-    const int32_t* runs;       // n_runs x (type, first, count): maximal runs of equal PrimRec.type
+    const int32_t* runs;       // n_runs x (type, first, count, first pair): maximal runs of equal PrimRec.type
+    const PairRec<R>* pairs;   // PairRec table of the parallelogram runs
     int32_t n_runs;
     int32_t pad0;
     // acceleration structure (n_bvh_prims == 0: linear scan over all prims)
@@ -102,6 +112,9 @@ struct RenderParams {
     uint32_t n_chunks;         // work items per pixel
     uint64_t n_items;          // n_chunks * width * height
     uint32_t seed_lo, seed_hi;
+    float inv_width, inv_height;          // 1 / width, 1 / height
+    float inv_spp, inv_x_strata, inv_y_strata;
+    uint32_t pad1;
     float* accum;              // width*height*3 radiance sums (atomicAdd target)
     unsigned long long* counters;  // see COUNTER_* below
     unsigned long long* work_counter;
