@@ -16,6 +16,7 @@
 
 #include "../../include/rrt.h"
 #include "rrt_launch.hpp"
+#include "rrt_lbvh.hpp"
 #include "rrt_types.hpp"
 
 namespace {
@@ -278,6 +279,114 @@ int device_scene(rrt_backend* be, const rrt_scene* sc_const, DeviceScene** out) 
     return RRT_OK;
 }
 
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+// Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO.
+const size_t kAutoBvhThreshold = 48;
+
+float round_down(double x) {
+    float f = (float)x;
+    return (double)f > x ? std::nextafterf(f, -INFINITY) : f;
+}
+float round_up(double x) {
+    float f = (float)x;
+    return (double)f < x ? std::nextafterf(f, INFINITY) : f;
+}
+
+// Builds the LBVH of a device scene on first use (shared by the f32 and f64 views: boxes are f32).
+int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
+    if (ds->has_bvh) return RRT_OK;
+    std::vector<int32_t> bounded, unbounded;  // scan-order indices
+    std::vector<float> lo, hi;
+    double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t g = 0; g < sc->prims.size(); ++g) {
+        const rrt_prim& p = sc->prims[g];
+        if (p.type == RRT_PRIM_PLANE) {
+            unbounded.push_back((int32_t)g);
+            continue;
+        }
+        double blo[3], bhi[3];
+        if (p.type == RRT_PRIM_SPHERE) {
+            for (int k = 0; k < 3; ++k) { blo[k] = p.v[k] - std::fabs(p.v[3]); bhi[k] = p.v[k] + std::fabs(p.v[3]); }
+        } else {
+            const int nv = p.type == RRT_PRIM_TRIANGLE ? 3 : 4;
+            for (int k = 0; k < 3; ++k) {
+                blo[k] = bhi[k] = p.v[k];
+                for (int j = 1; j < nv; ++j) {
+                    blo[k] = std::fmin(blo[k], p.v[3 * j + k]);
+                    bhi[k] = std::fmax(bhi[k], p.v[3 * j + k]);
+                }
+            }
+        }
+        // pad: the f32 ray test may accept a point a few 1e-7 (relative) outside the exact primitive
+        double ext = std::fmax(std::fmax(bhi[0] - blo[0], bhi[1] - blo[1]), bhi[2] - blo[2]);
+        double mag = 0;
+        for (int k = 0; k < 3; ++k) mag = std::fmax(mag, std::fmax(std::fabs(blo[k]), std::fabs(bhi[k])));
+        double pad = 1e-4 * ext + 4e-6 * mag + 1e-30;
+        for (int k = 0; k < 3; ++k) {
+            lo.push_back(round_down(blo[k] - pad));
+            hi.push_back(round_up(bhi[k] + pad));
+            slo[k] = std::fmin(slo[k], blo[k]);
+            shi[k] = std::fmax(shi[k], bhi[k]);
+        }
+        bounded.push_back((int32_t)g);
+    }
+    const int n = (int)bounded.size();
+    int rc;
+    const int32_t* d_lin = nullptr;
+    if ((rc = upload(ds, unbounded, &d_lin, be->stream)) != RRT_OK) return rc;
+    const int32_t* d_slot = nullptr;
+    const rrt::BvhNode* d_nodes = nullptr;
+    if (n == 1) {
+        if ((rc = upload(ds, bounded, &d_slot, be->stream)) != RRT_OK) return rc;
+    } else if (n >= 2) {
+        DevBuf dlo, dhi;
+        HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));
+        HIP_TRY(dhi.alloc(sizeof(float) * 3 * n));
+        HIP_TRY(hipMemcpyAsync(dlo.p, lo.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
+        HIP_TRY(hipMemcpyAsync(dhi.p, hi.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
+        void *nodes = nullptr, *slots = nullptr;
+        HIP_TRY(hipMalloc(&nodes, sizeof(rrt::BvhNode) * (size_t)(n - 1)));
+        ds->allocs.push_back(nodes);
+        HIP_TRY(hipMalloc(&slots, sizeof(int32_t) * (size_t)n));
+        ds->allocs.push_back(slots);
+        float flo[3], fhi[3];
+        for (int k = 0; k < 3; ++k) { flo[k] = round_down(slo[k]); fhi[k] = round_up(shi[k]); }
+        HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, (rrt::BvhNode*)nodes,
+                                (int*)slots, be->stream));
+        // sorted slot -> index among the bounded primitives -> scan-order index
+        std::vector<int32_t> map((size_t)n);
+        HIP_TRY(hipMemcpy(map.data(), slots, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            if (map[i] < 0 || map[i] >= n) return fail(RRT_ERR_HIP, "LBVH build produced an invalid slot table");
+            map[i] = bounded[(size_t)map[i]];
+        }
+        HIP_TRY(hipMemcpy(slots, map.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+        d_nodes = (const rrt::BvhNode*)nodes;
+        d_slot = (const int32_t*)slots;
+    }
+    HIP_TRY(hipStreamSynchronize(be->stream));
+    ds->v32.nodes = ds->v64.nodes = d_nodes;
+    ds->v32.bvh_prim = ds->v64.bvh_prim = d_slot;
+    ds->v32.linear_prim = ds->v64.linear_prim = d_lin;
+    ds->v32.n_bvh_prims = ds->v64.n_bvh_prims = n;
+    ds->v32.n_linear_prims = ds->v64.n_linear_prims = (int32_t)unbounded.size();
+    ds->has_bvh = true;
+    return RRT_OK;
+}
+
+// AUTO: tree for scenes too large for the wave-uniform scan; LBVH: always; LINEAR: never.
+int resolve_accel(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, uint32_t accel, bool* use_bvh) {
+    *use_bvh = accel == RRT_ACCEL_LBVH || (accel == RRT_ACCEL_AUTO && sc->prims.size() > kAutoBvhThreshold);
+    return *use_bvh ? ensure_bvh(be, sc, ds) : RRT_OK;
+}
+
 bool is_device_pointer(const void* p) {
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
@@ -287,14 +396,6 @@ bool is_device_pointer(const void* p) {
     }
     return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
-
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-};
 
 int check_backend(rrt_backend* be) {
     if (!be) return fail(RRT_ERR_INVALID, "backend is NULL");
@@ -319,9 +420,10 @@ int closest_hit_call(rrt_backend* be, const rrt_scene* scene, uint32_t precision
         }
         return RRT_OK;
     }
-    if (accel == RRT_ACCEL_LBVH) return fail(RRT_ERR_UNSUPPORTED, "LBVH traversal is not built into this library yet");
     DeviceScene* ds = nullptr;
     if ((rc = device_scene(be, scene, &ds)) != RRT_OK) return rc;
+    bool use_bvh = false;
+    if ((rc = resolve_accel(be, scene, ds, accel, &use_bvh)) != RRT_OK) return rc;
     const size_t per = primary ? 1 : 3;
     DevBuf da, db, doid, dpid, dt;
     HIP_TRY(da.alloc(n * per * sizeof(double)));
@@ -332,10 +434,10 @@ int closest_hit_call(rrt_backend* be, const rrt_scene* scene, uint32_t precision
     HIP_TRY(hipMemcpyAsync(da.p, a, n * per * sizeof(double), hipMemcpyHostToDevice, be->stream));
     HIP_TRY(hipMemcpyAsync(db.p, b, n * per * sizeof(double), hipMemcpyHostToDevice, be->stream));
     if (precision == RRT_PRECISION_F64)
-        HIP_TRY(rrt::launch_intersect(ds->v64, primary, n, (const double*)da.p, (const double*)db.p,
+        HIP_TRY(rrt::launch_intersect(ds->v64, use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
                                       (int32_t*)doid.p, (int32_t*)dpid.p, (double*)dt.p, be->stream));
     else
-        HIP_TRY(rrt::launch_intersect(ds->v32, primary, n, (const double*)da.p, (const double*)db.p,
+        HIP_TRY(rrt::launch_intersect(ds->v32, use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
                                       (int32_t*)doid.p, (int32_t*)dpid.p, (double*)dt.p, be->stream));
     HIP_TRY(hipMemcpyAsync(object_id, doid.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipMemcpyAsync(prim_id, dpid.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
@@ -538,10 +640,10 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     if ((rc = validate_render_desc(desc)) != RRT_OK) return rc;
     if (desc->pipeline == RRT_PIPELINE_WAVEFRONT)
         return fail(RRT_ERR_UNSUPPORTED, "the wavefront pipeline is not built into this library yet");
-    if (desc->accel == RRT_ACCEL_LBVH)
-        return fail(RRT_ERR_UNSUPPORTED, "LBVH traversal is not built into this library yet");
     DeviceScene* ds = nullptr;
     if ((rc = device_scene(be, scene, &ds)) != RRT_OK) return rc;
+    bool use_bvh = false;
+    if ((rc = resolve_accel(be, scene, ds, desc->accel, &use_bvh)) != RRT_OK) return rc;
 
     const size_t n_pixels = (size_t)desc->width * desc->height;
     const bool on_device = is_device_pointer(rgb_sum);
@@ -568,9 +670,9 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     HIP_TRY(hipEventRecord(be->ev0, be->stream));
     if (desc->max_depth > 0) {
         if (desc->precision == RRT_PRECISION_F64)
-            HIP_TRY(rrt::launch_render_fused(ds->v64, rp, n_blocks, be->stream));
+            HIP_TRY(rrt::launch_render_fused(ds->v64, use_bvh, rp, n_blocks, be->stream));
         else
-            HIP_TRY(rrt::launch_render_fused(ds->v32, rp, n_blocks, be->stream));
+            HIP_TRY(rrt::launch_render_fused(ds->v32, use_bvh, rp, n_blocks, be->stream));
     }
     HIP_TRY(hipEventRecord(be->ev1, be->stream));
 

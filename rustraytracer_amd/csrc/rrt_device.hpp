@@ -266,38 +266,50 @@ RRT_DEV R min3(R a, R b, R c) {
     return fmin(fmin(a, b), c);
 }
 
+// best - t with t already rounded.  t is a product (numerator x reciprocal); left to itself the
+// compiler contracts "best - n * r" into one FMA, which subtracts the UNROUNDED product and can
+// call two bit-identical distances different.  The tie rule needs the comparison the reference
+// makes: between two stored f64/f32 values.
+template <typename R>
+RRT_DEV R headroom(R best_t, R t) {
+#pragma clang fp contract(off)
+    return best_t - t;
+}
+
 // TYPE is a compile-time constant in the run loops of the linear scan (no per-primitive
 // dispatch) and a per-lane value in tree leaves.
 template <typename R, int TYPE>
 RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
     const R RRT_CONSTANT* f = p->f;
     if (TYPE >= PRIM_TRIANGLE) {
+        // (the order of operations is the one of scan_run_pairs: a primitive gets the same t and
+        // the same verdict from the wave-uniform scan, the packed pair scan and a tree leaf)
         R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-        R no = f[3] - (f[0] * o.x + f[1] * o.y + f[2] * o.z);
+        R no = ((f[3] - f[0] * o.x) - f[1] * o.y) - f[2] * o.z;
         R t = no * Num<R>::rcp(nd);
         t_out = t;
         V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-        R a = f[4] * P.x + f[5] * P.y + f[6] * P.z + f[7];
-        R b = f[8] * P.x + f[9] * P.y + f[10] * P.z + f[11];
+        R a = f[4] * P.x + (f[5] * P.y + (f[6] * P.z + f[7]));
+        R b = f[8] * P.x + (f[9] * P.y + (f[10] * P.z + f[11]));
         R det_ok = Num<R>::abs(nd) - Num<R>::eps();
         if (TYPE == PRIM_PGRAM) {
             // parallelogram: alpha' = 1 - alpha and beta' = 1 - beta, so the two-triangle
             // test is 0 <= alpha, beta <= 1; a and b arrive shifted by -1/2
             R h = min3(R(0.5) - Num<R>::abs(a), R(0.5) - Num<R>::abs(b), det_ok);
-            return min3(h, t - Num<R>::tmin(), best_t - t) >= R(0);
+            return min3(h, t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
         }
         if (TYPE == PRIM_QUAD) {
-            R a2 = f[12] * P.x + f[13] * P.y + f[14] * P.z + f[15];
-            R b2 = f[16] * P.x + f[17] * P.y + f[18] * P.z + f[19];
+            R a2 = f[12] * P.x + (f[13] * P.y + (f[14] * P.z + f[15]));
+            R b2 = f[16] * P.x + (f[17] * P.y + (f[18] * P.z + f[19]));
             R nd2 = f[20] * d.x + f[21] * d.y + f[22] * d.z;
             R second = min3(a2, b2, Num<R>::abs(nd2) - Num<R>::eps());  // the (v2, v3, v1) corner
             R inside = fmax(R(1) - (a + b), second);                      // alpha + beta <= 1, or that corner
             R h = min3(min3(a, b, inside), det_ok, t - Num<R>::tmin());
-            return fmin(h, best_t - t) >= R(0);
+            return fmin(h, headroom(best_t, t)) >= R(0);
         }
         // triangle: u, v >= 0, u <= 1, u + v <= 1, and an OPEN t interval
         R h = min3(min3(a, b, R(1) - a), R(1) - (a + b), det_ok);
-        return (h >= R(0)) && (fmin(t - Num<R>::tmin(), best_t - t) > R(0));
+        return (h >= R(0)) && (fmin(t - Num<R>::tmin(), headroom(best_t, t)) > R(0));
     }
     if (TYPE == PRIM_SPHERE) {  // src/shapes/sphere.rs:58-96
         V3<R> l = mk<R>(f[0] - o.x, f[1] - o.y, f[2] - o.z);
@@ -318,14 +330,14 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
         R t1 = t_ca + t_hc;
         if (t0 < Num<R>::tmin()) t0 = t1;
         t_out = t0;
-        return min3(fmin(x, d2), t0 - Num<R>::tmin(), best_t - t0) >= R(0);
+        return min3(fmin(x, d2), t0 - Num<R>::tmin(), headroom(best_t, t0)) >= R(0);
     }
     // plane, src/shapes/plane.rs:25-44
     R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-    R no = f[3] - (f[0] * o.x + f[1] * o.y + f[2] * o.z);
+    R no = ((f[3] - f[0] * o.x) - f[1] * o.y) - f[2] * o.z;
     R t = no * Num<R>::rcp(nd);
     t_out = t;
-    return min3(Num<R>::abs(nd) - Num<R>::eps(), t - Num<R>::tmin(), best_t - t) >= R(0);
+    return min3(Num<R>::abs(nd) - Num<R>::eps(), t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
 }
 
 template <typename R>
@@ -379,11 +391,11 @@ RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int
         R2 b = f[8] * px + (f[9] * py + (f[10] * pz + f[11]));
         R2 tm = t - Num<R>::tmin();
         R h0 = min3(R(0.5) - Num<R>::abs(a.x), R(0.5) - Num<R>::abs(b.x), Num<R>::abs(nd.x) - Num<R>::eps());
-        const bool ok0 = min3(h0, tm.x, best_t - t.x) >= R(0);
+        const bool ok0 = min3(h0, tm.x, headroom(best_t, (R)t.x)) >= R(0);
         best_t = ok0 ? t.x : best_t;
         best_g = ok0 ? first + 2 * k : best_g;
         R h1 = min3(R(0.5) - Num<R>::abs(a.y), R(0.5) - Num<R>::abs(b.y), Num<R>::abs(nd.y) - Num<R>::eps());
-        const bool ok1 = min3(h1, tm.y, best_t - t.y) >= R(0);
+        const bool ok1 = min3(h1, tm.y, headroom(best_t, (R)t.y)) >= R(0);
         best_t = ok1 ? t.y : best_t;
         best_g = ok1 ? first + 2 * k + 1 : best_g;
     }

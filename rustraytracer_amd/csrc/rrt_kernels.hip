@@ -12,6 +12,7 @@
 
 #include <cstdlib>
 
+#include "rrt_bvh.hpp"
 #include "rrt_launch.hpp"
 #include "rrt_shade.hpp"
 
@@ -20,6 +21,7 @@ namespace rrt {
 // Closest hit over the whole scene.  Returns the scan-order primitive index or -1.
 template <typename R, bool BVH>
 RRT_DEV int closest_hit(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t, HitCounters& hc) {
+    if (BVH) return closest_hit_bvh<R>(sv, o, d, t, hc);
     R best_t = Num<R>::tmax();
     int best_g = -1;
     scan_linear(sv, o, d, best_t, best_g, hc);
@@ -220,7 +222,15 @@ render_fused(SceneView<R> sv, RenderParams rp) {
             have_ray = scatter<R>(rp, path, mode, n, m, u2, v2);
         }
     }
-    if (!BVH) hc.prim_tests = c_rays * (uint32_t)sv.n_prims;  // a linear scan tests every primitive
+    if (!BVH) {
+        hc.prim_tests = c_rays * (uint32_t)sv.n_prims;  // a linear scan tests every primitive
+    } else {
+        // tree traversal counts per lane: fold the wave's 64 counters into lane 0
+        for (int off = 32; off > 0; off >>= 1) {
+            hc.prim_tests += __shfl_xor(hc.prim_tests, off);
+            hc.node_tests += __shfl_xor(hc.node_tests, off);
+        }
+    }
 
     if (lane == 0) {
         atomicAdd(&rp.counters[COUNTER_RAYS], (unsigned long long)c_rays);
@@ -267,40 +277,50 @@ postprocess_kernel(const float* __restrict__ sum, double inv_spp, PostParams pp,
 
 // ------------------------------------------------------------------ launchers
 template <typename R>
-static hipError_t launch_intersect_t(const SceneView<R>& sv, bool primary, size_t n, const double* a,
+static hipError_t launch_intersect_t(const SceneView<R>& sv, bool bvh, bool primary, size_t n, const double* a,
                                      const double* b, int32_t* oid, int32_t* pid, double* t,
                                      hipStream_t stream) {
     if (n == 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((n + 255) / 256));
-    if (primary)
-        hipLaunchKernelGGL((intersect_kernel<R, false, true>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
-    else
-        hipLaunchKernelGGL((intersect_kernel<R, false, false>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+    if (bvh) {
+        if (primary)
+            hipLaunchKernelGGL((intersect_kernel<R, true, true>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+        else
+            hipLaunchKernelGGL((intersect_kernel<R, true, false>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+    } else {
+        if (primary)
+            hipLaunchKernelGGL((intersect_kernel<R, false, true>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+        else
+            hipLaunchKernelGGL((intersect_kernel<R, false, false>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_intersect(const SceneView<float>& sv, bool primary, size_t n, const double* a,
+hipError_t launch_intersect(const SceneView<float>& sv, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s) {
-    return launch_intersect_t<float>(sv, primary, n, a, b, oid, pid, t, s);
+    return launch_intersect_t<float>(sv, bvh, primary, n, a, b, oid, pid, t, s);
 }
-hipError_t launch_intersect(const SceneView<double>& sv, bool primary, size_t n, const double* a,
+hipError_t launch_intersect(const SceneView<double>& sv, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s) {
-    return launch_intersect_t<double>(sv, primary, n, a, b, oid, pid, t, s);
+    return launch_intersect_t<double>(sv, bvh, primary, n, a, b, oid, pid, t, s);
 }
 
 template <typename R>
-static hipError_t launch_render_fused_t(const SceneView<R>& sv, const RenderParams& rp, int n_blocks,
+static hipError_t launch_render_fused_t(const SceneView<R>& sv, bool bvh, const RenderParams& rp, int n_blocks,
                                         hipStream_t stream) {
     // RRT_DEBUG_LDS_BYTES: occupancy experiments only (unused dynamic LDS caps the blocks per CU)
     static const size_t lds = [] { const char* e = getenv("RRT_DEBUG_LDS_BYTES"); return e ? (size_t)atol(e) : (size_t)0; }();
-    hipLaunchKernelGGL((render_fused<R, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
+    if (bvh)
+        hipLaunchKernelGGL((render_fused<R, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
+    else
+        hipLaunchKernelGGL((render_fused<R, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
     return hipGetLastError();
 }
-hipError_t launch_render_fused(const SceneView<float>& sv, const RenderParams& rp, int n_blocks, hipStream_t s) {
-    return launch_render_fused_t<float>(sv, rp, n_blocks, s);
+hipError_t launch_render_fused(const SceneView<float>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
+    return launch_render_fused_t<float>(sv, bvh, rp, n_blocks, s);
 }
-hipError_t launch_render_fused(const SceneView<double>& sv, const RenderParams& rp, int n_blocks, hipStream_t s) {
-    return launch_render_fused_t<double>(sv, rp, n_blocks, s);
+hipError_t launch_render_fused(const SceneView<double>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
+    return launch_render_fused_t<double>(sv, bvh, rp, n_blocks, s);
 }
 
 hipError_t launch_sampler_values(const RenderParams& rp, uint32_t pixel, float* out, hipStream_t stream) {

@@ -15,13 +15,13 @@ struct PostParams {
 };
 
 // a, b: PRIMARY ? (u[n], v[n]) : (origins[3n], dirs[3n]); all pointers are device memory
-hipError_t launch_intersect(const SceneView<float>& sv, bool primary, size_t n, const double* a,
+hipError_t launch_intersect(const SceneView<float>& sv, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s);
-hipError_t launch_intersect(const SceneView<double>& sv, bool primary, size_t n, const double* a,
+hipError_t launch_intersect(const SceneView<double>& sv, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s);
 
-hipError_t launch_render_fused(const SceneView<float>& sv, const RenderParams& rp, int n_blocks, hipStream_t s);
-hipError_t launch_render_fused(const SceneView<double>& sv, const RenderParams& rp, int n_blocks, hipStream_t s);
+hipError_t launch_render_fused(const SceneView<float>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
+hipError_t launch_render_fused(const SceneView<double>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
 
 hipError_t launch_sampler_values(const RenderParams& rp, uint32_t pixel, float* out, hipStream_t stream);
 

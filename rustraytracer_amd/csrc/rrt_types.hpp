@@ -67,14 +67,18 @@ struct MatRec {
     int32_t pad[2];
 };
 
-// LBVH node (see lbvh.hip).  Children < 0 encode leaves: ~child = sorted
-// primitive slot.  Boxes are stored padded outward so that an f32 slab test
-// never rejects a box the exact arithmetic would enter.
+// LBVH node (rrt_lbvh.hip): the boxes of both children and the child links.  child < 0 encodes a
+// leaf: ~child = sorted slot.  Boxes are f32, rounded outward and padded on the host, so a slab
+// test never rejects a box whose primitive the ray test would accept.
 struct BvhNode {
-    float lo[3];
-    int32_t left;
-    float hi[3];
-    int32_t right;
+    float lo0[3];
+    int32_t c0;
+    float hi0[3];
+    int32_t c1;
+    float lo1[3];
+    int32_t pad0;
+    float hi1[3];
+    int32_t pad1;
 };
 
 template <typename R>
@@ -93,9 +97,9 @@ struct SceneView {
     int32_t n_runs;
     int32_t pad0;
     // acceleration structure (n_bvh_prims == 0: linear scan over all prims)
-    const BvhNode* nodes;
-    const int32_t* bvh_prim;   // sorted slot -> scan-order primitive index
-    const int32_t* linear_prim; // primitives kept out of the tree (planes), scan order
+    const BvhNode* nodes;       // n_bvh_prims - 1 nodes, node 0 is the root
+    const int32_t* bvh_prim;    // sorted slot -> scan-order primitive index
+    const int32_t* linear_prim; // primitives kept out of the tree (unbounded planes), scan order
     int32_t n_bvh_prims;
     int32_t n_linear_prims;
 };
