@@ -18,6 +18,7 @@
 #include "rrt_launch.hpp"
 #include "rrt_lbvh.hpp"
 #include "rrt_types.hpp"
+#include "rrt_wavefront.hpp"
 
 namespace {
 
@@ -184,6 +185,10 @@ struct rrt_backend {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long* d_counters = nullptr;  // COUNTER_COUNT + 1 (the last one is the work counter)
+    // wavefront pipeline: queues and control block, allocated on first use and kept
+    void* wf_mem = nullptr;
+    uint32_t wf_capacity = 0;
+    rrt::WfParams wf{};
 };
 
 namespace {
@@ -514,6 +519,99 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
     return rp;
 }
 
+// ------------------------------------------------------------------ wavefront pipeline
+// Paths per queue.  4 Mi paths = 448 MiB for the two queues; one trip then moves ~0.5 GB through
+// HBM and costs two kernel launches, so larger queues buy nothing.
+const uint32_t kWfDefaultCapacity = 1u << 22;
+
+int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity) {
+    if (be->wf_mem && be->wf_capacity == capacity) return RRT_OK;
+    if (be->wf_mem) {
+        HIP_TRY(hipStreamSynchronize(be->stream));
+        HIP_TRY(hipFree(be->wf_mem));
+        be->wf_mem = nullptr;
+        be->wf_capacity = 0;
+    }
+    const size_t n = capacity;
+    const size_t per_queue = n * (sizeof(float4) + sizeof(float2) + sizeof(float2) + sizeof(float4) + sizeof(uint2));
+    const size_t cursors = (n / 64) * sizeof(rrt::WfWaveCursor);
+    const size_t rows = (n / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
+    const size_t total = 2 * per_queue + cursors + rows + 256;
+    HIP_TRY(hipMalloc(&be->wf_mem, total));
+    char* p = (char*)be->wf_mem;
+    auto take = [&p](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    // capacity is a multiple of 1024, so every array below is a multiple of 256 bytes long except
+    // the control block at the end, which the spare 256 bytes cover
+    rrt::WfParams& wp = be->wf;
+    std::memset(&wp, 0, sizeof(wp));
+    for (int k = 0; k < 2; ++k) {
+        wp.q[k].o_dx = (float4*)take(n * sizeof(float4));
+        wp.q[k].dyz = (float2*)take(n * sizeof(float2));
+        wp.q[k].hit = (float2*)take(n * sizeof(float2));
+        wp.q[k].beta_pix = (float4*)take(n * sizeof(float4));
+        wp.q[k].smp = (uint2*)take(n * sizeof(uint2));
+    }
+    wp.cursors = (rrt::WfWaveCursor*)take(cursors);
+    wp.block_counters = (unsigned long long*)take(rows);
+    wp.ctl = (rrt::WfControl*)take(sizeof(rrt::WfControl));
+    wp.capacity = capacity;
+    be->wf_capacity = capacity;
+    return RRT_OK;
+}
+
+// Runs the trips of the wavefront pipeline until every sample of the call is traced; fills
+// `counters` like the fused kernel does.
+int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_bvh, rrt::RenderParams rp,
+                     unsigned long long* counters) {
+    if (rp.max_depth > rrt::WF_MAX_DEPTH)
+        return fail(RRT_ERR_UNSUPPORTED, "the wavefront pipeline packs the path depth into 9 bits: max_depth %u > %u",
+                    rp.max_depth, rrt::WF_MAX_DEPTH);
+    const uint64_t n_pixels = (uint64_t)rp.width * rp.height;
+    const uint64_t total = n_pixels * rp.n_samples;
+    uint32_t capacity = kWfDefaultCapacity;
+    if (const char* e = getenv("RRT_DEBUG_WF_CAPACITY")) {  // experiments and tests
+        long v = atol(e);
+        if (v >= 64 && v <= (1l << 26)) capacity = (uint32_t)v;
+    }
+    const uint32_t block = (uint32_t)rrt::WF_SHADE_BLOCK;
+    if ((uint64_t)capacity > total) capacity = (uint32_t)total;
+    capacity = (capacity + block - 1) / block * block;
+    int rc = ensure_wavefront_buffers(be, capacity);
+    if (rc != RRT_OK) return rc;
+    rrt::WfParams wp = be->wf;
+    wp.stride_s = (uint32_t)(capacity / n_pixels);
+    wp.stride_p = (uint32_t)(capacity % n_pixels);
+    const size_t rows_bytes = (size_t)(capacity / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
+    HIP_TRY(hipMemsetAsync(wp.block_counters, 0, rows_bytes, be->stream));
+    HIP_TRY(rrt::wf_launch_init(rp, wp, be->stream));
+
+    // A trip starts at most `capacity` samples, so the first total / capacity trips cannot be the
+    // last; after that the live count is read back every few trips (an idle trip costs two
+    // near-empty launches).
+    const uint64_t sure = total / capacity;
+    const uint64_t check_every = 4;
+    rrt::WfControl ctl;
+    int parity = 0;
+    for (uint64_t trip = 0;; ++trip) {
+        HIP_TRY(rrt::wf_launch_shade(sv, rp, wp, parity, be->stream));
+        parity ^= 1;
+        HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, be->stream));
+        if (trip >= sure && (trip - sure) % check_every == 0) {
+            HIP_TRY(hipMemcpyAsync(&ctl, wp.ctl, sizeof(ctl), hipMemcpyDeviceToHost, be->stream));
+            HIP_TRY(hipStreamSynchronize(be->stream));
+            if (ctl.count[parity] == 0) break;
+        }
+    }
+    std::vector<unsigned long long> rows(rows_bytes / sizeof(unsigned long long));
+    HIP_TRY(hipMemcpyAsync(rows.data(), wp.block_counters, rows_bytes, hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipStreamSynchronize(be->stream));
+    for (int k = 0; k < rrt::COUNTER_COUNT; ++k) counters[k] = 0;
+    for (size_t i = 0; i < rows.size(); ++i) counters[i % rrt::COUNTER_COUNT] += rows[i];
+    counters[rrt::COUNTER_RAYS] = ctl.rays;
+    if (!use_bvh) counters[rrt::COUNTER_PRIM_TESTS] = ctl.rays * (unsigned long long)sv.n_prims;
+    return RRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -612,6 +710,7 @@ void rrt_backend_destroy(rrt_backend* be) {
     if (be->ev0) (void)hipEventDestroy(be->ev0);
     if (be->ev1) (void)hipEventDestroy(be->ev1);
     if (be->d_counters) (void)hipFree(be->d_counters);
+    if (be->wf_mem) (void)hipFree(be->wf_mem);
     delete be;
 }
 
@@ -638,12 +737,17 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
     if (!rgb_sum) return fail(RRT_ERR_INVALID, "rgb_sum is NULL");
     if ((rc = validate_render_desc(desc)) != RRT_OK) return rc;
-    if (desc->pipeline == RRT_PIPELINE_WAVEFRONT)
-        return fail(RRT_ERR_UNSUPPORTED, "the wavefront pipeline is not built into this library yet");
+    if (desc->pipeline == RRT_PIPELINE_WAVEFRONT && desc->precision == RRT_PRECISION_F64)
+        return fail(RRT_ERR_UNSUPPORTED, "the wavefront pipeline keeps its queues in f32; use the fused pipeline for f64");
     DeviceScene* ds = nullptr;
     if ((rc = device_scene(be, scene, &ds)) != RRT_OK) return rc;
     bool use_bvh = false;
     if ((rc = resolve_accel(be, scene, ds, desc->accel, &use_bvh)) != RRT_OK) return rc;
+    // AUTO: tree traversal wants many waves in flight, which the register-lean closest-hit kernel of
+    // the wavefront pipeline has; a scan over a few primitives is fastest with the path in registers
+    const bool wavefront = desc->pipeline == RRT_PIPELINE_WAVEFRONT ||
+                           (desc->pipeline == RRT_PIPELINE_AUTO && use_bvh && desc->precision == RRT_PRECISION_F32 &&
+                            desc->max_depth <= rrt::WF_MAX_DEPTH);
 
     const size_t n_pixels = (size_t)desc->width * desc->height;
     const bool on_device = is_device_pointer(rgb_sum);
@@ -667,8 +771,11 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     int n_blocks = (int)(want < max_blocks ? want : max_blocks);
     if (n_blocks < 1) n_blocks = 1;
 
+    unsigned long long counters[rrt::COUNTER_COUNT + 1];
     HIP_TRY(hipEventRecord(be->ev0, be->stream));
-    if (desc->max_depth > 0) {
+    if (desc->max_depth > 0 && wavefront) {
+        if ((rc = render_wavefront(be, ds->v32, use_bvh, rp, counters)) != RRT_OK) return rc;
+    } else if (desc->max_depth > 0) {
         if (desc->precision == RRT_PRECISION_F64)
             HIP_TRY(rrt::launch_render_fused(ds->v64, use_bvh, rp, n_blocks, be->stream));
         else
@@ -676,8 +783,8 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     }
     HIP_TRY(hipEventRecord(be->ev1, be->stream));
 
-    unsigned long long counters[rrt::COUNTER_COUNT + 1];
-    HIP_TRY(hipMemcpyAsync(counters, be->d_counters, sizeof(counters), hipMemcpyDeviceToHost, be->stream));
+    if (!wavefront || desc->max_depth == 0)
+        HIP_TRY(hipMemcpyAsync(counters, be->d_counters, sizeof(counters), hipMemcpyDeviceToHost, be->stream));
     std::vector<float> host_tmp;
     if (!on_device) {
         host_tmp.resize(n_pixels * 3);

@@ -18,17 +18,6 @@
 
 namespace rrt {
 
-// Closest hit over the whole scene.  Returns the scan-order primitive index or -1.
-template <typename R, bool BVH>
-RRT_DEV int closest_hit(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t, HitCounters& hc) {
-    if (BVH) return closest_hit_bvh<R>(sv, o, d, t, hc);
-    R best_t = Num<R>::tmax();
-    int best_g = -1;
-    scan_linear(sv, o, d, best_t, best_g, hc);
-    t = best_t;
-    return best_g;
-}
-
 // ------------------------------------------------------------------ parity kernels
 template <typename R, bool BVH, bool PRIMARY>
 __global__ void __launch_bounds__(256)

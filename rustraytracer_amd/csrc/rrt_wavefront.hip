@@ -1,0 +1,273 @@
+// Wavefront path tracer kernels for gfx950 (see rrt_wavefront.hpp for the queue layout).
+#include <hip/hip_runtime.h>
+
+#include "rrt_bvh.hpp"
+#include "rrt_shade.hpp"
+#include "rrt_wavefront.hpp"
+
+namespace rrt {
+
+namespace {
+
+RRT_DEV uint32_t lane_rank(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Per-block event counts: waves add into LDS, then one thread per counter adds the block's total to
+// the block's own row in global memory (rows are summed on the host after the render), so the
+// per-trip kernels issue no global atomics for statistics.
+struct BlockCounters {
+    uint32_t v[COUNTER_COUNT];
+};
+
+RRT_DEV void counters_flush(const BlockCounters& lds, unsigned long long* rows) {
+    if (threadIdx.x < COUNTER_COUNT && lds.v[threadIdx.x])
+        rows[(size_t)blockIdx.x * COUNTER_COUNT + threadIdx.x] += lds.v[threadIdx.x];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ set-up
+// Marks every slot of queue 0 empty (the first wf_shade then fills it with camera samples),
+// positions the per-wave sample cursors and clears the control block.
+__global__ void __launch_bounds__(256) wf_init(RenderParams rp, WfParams wp) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < wp.capacity) wp.q[0].hit[i] = make_float2(0.f, __int_as_float(WF_EMPTY));
+    const uint32_t n_waves = wp.capacity / 64u;
+    if (i < n_waves) {
+        const unsigned long long first = (unsigned long long)i * 64ull;
+        const unsigned long long n_pixels = (unsigned long long)rp.width * rp.height;
+        WfWaveCursor c;
+        c.s = (uint32_t)(first / n_pixels);
+        c.p = (uint32_t)(first % n_pixels);
+        c.off = 0;
+        c.pad = 0;
+        wp.cursors[i] = c;
+    }
+    if (i == 0) {
+        wp.ctl->count[0] = wp.capacity;
+        wp.ctl->count[1] = 0;
+        wp.ctl->rays = 0;
+    }
+}
+
+// ------------------------------------------------------------------ closest hit
+// One ray per lane.  The linear scan reads primitive records wave-uniformly, so all 64 lanes of a
+// wave that holds at least one ray run it; lanes past the end of the queue repeat the last ray.
+template <bool BVH>
+__global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> sv, WfParams wp, int parity) {
+    __shared__ BlockCounters s_ctr;
+    const uint32_t n_in = wp.ctl->count[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wp.ctl->count[parity ^ 1] = 0;  // the output counter of the wf_shade that follows
+        wp.ctl->rays += n_in;
+    }
+    if (blockIdx.x * (uint32_t)WF_HIT_BLOCK >= n_in) return;
+    if (BVH) {
+        if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    const WfQueue& q = wp.q[parity];
+    const uint32_t idx = blockIdx.x * (uint32_t)WF_HIT_BLOCK + threadIdx.x;
+    const uint32_t j = idx < n_in ? idx : n_in - 1u;
+    const float4 a = q.o_dx[j];
+    const float2 b = q.dyz[j];
+    HitCounters hc{0, 0};
+    float t;
+    const int g = closest_hit<float, BVH>(sv, mk<float>(a.x, a.y, a.z), mk<float>(a.w, b.x, b.y), t, hc);
+    if (idx < n_in) q.hit[idx] = make_float2(t, __int_as_float(g >= 0 ? g : WF_MISS));
+    if (BVH) {
+        if (idx >= n_in) hc.prim_tests = hc.node_tests = 0;
+        for (int off = 32; off > 0; off >>= 1) {
+            hc.prim_tests += __shfl_xor(hc.prim_tests, off);
+            hc.node_tests += __shfl_xor(hc.node_tests, off);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            atomicAdd(&s_ctr.v[COUNTER_PRIM_TESTS], hc.prim_tests);
+            atomicAdd(&s_ctr.v[COUNTER_NODE_TESTS], hc.node_tests);
+        }
+        __syncthreads();
+        counters_flush(s_ctr, wp.block_counters);
+    }
+}
+
+// ------------------------------------------------------------------ shade + regenerate + compact
+// Lane i owns slot i of the input queue.  After the hit is processed (emission, Russian roulette)
+// the lane either scatters its path or, if it holds none any more, starts the next camera sample of
+// its wave's cursor.  Every lane that ends the trip with a ray writes it to the output queue at
+//   block base (one atomicAdd per block) + rays of the earlier waves of the block + rank in the wave.
+__global__ void __launch_bounds__(WF_SHADE_BLOCK)
+wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity) {
+    typedef float R;
+    constexpr int WAVES = WF_SHADE_BLOCK / 64;
+    __shared__ BlockCounters s_ctr;
+    __shared__ uint32_t s_wave_rays[WAVES];
+    __shared__ uint32_t s_base;
+
+    const uint32_t idx = blockIdx.x * (uint32_t)WF_SHADE_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t gwave = __builtin_amdgcn_readfirstlane(idx >> 6);
+    const WfQueue& qi = wp.q[parity];
+    const WfQueue& qo = wp.q[parity ^ 1];
+    const uint32_t n_in = wp.ctl->count[parity];
+    const uint32_t n_pixels = rp.width * rp.height;
+
+    if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
+    __syncthreads();
+
+    Path<R> path;
+    path.o = path.d = path.beta = mk<R>(0, 0, 0);
+    path.depth = 0;
+    path.smp = Sampler{0, 0, 0, 0, 4};
+    uint32_t pixel = 0;
+    int mode = MODE_NEW, counted = -1;
+    bool bad = false;
+    V3<R> n = mk<R>(0, 0, 0);
+    MatRec<R> m;
+    m.r = m.g = m.b = m.param = R(0);
+    m.type = 0;
+
+    if (idx < n_in) {
+        const float2 h = qi.hit[idx];
+        const int g = __float_as_int(h.y);
+        if (g >= 0) {
+            const float4 a = qi.o_dx[idx];
+            const float2 b = qi.dyz[idx];
+            const float4 c = qi.beta_pix[idx];
+            const uint2 s = qi.smp[idx];
+            path.o = mk<R>(a.x, a.y, a.z);
+            path.d = mk<R>(a.w, b.x, b.y);
+            path.beta = mk<R>(c.x, c.y, c.z);
+            pixel = __float_as_uint(c.w);
+            path.smp.pixkey = pixel_key(rp.seed_lo, rp.seed_hi, pixel);
+            path.smp.sample = s.x;
+            path.smp.key = sample_key(path.smp.pixkey, s.x);
+            path.smp.ctr = s.y & 0xfffffu;
+            path.smp.dim = (s.y >> 20) & 7u;
+            path.depth = s.y >> 23;
+            V3<R> acc = mk<R>(0, 0, 0);
+            mode = process_hit<R>(sv, rp, path, g, h.x, acc, n, m, bad, counted);
+            // only an emitter adds radiance, and it ends the path: at most one add per sample
+            if (acc.x != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 0], acc.x);
+            if (acc.y != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 1], acc.y);
+            if (acc.z != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 2], acc.z);
+        }
+    }
+
+    // -- the next camera samples of this wave go to the lanes without a path
+    const bool vacant = mode == MODE_NEW;
+    const unsigned long long vacant_mask = __ballot(vacant);
+    bool start = false;
+    if (vacant_mask) {
+        WfWaveCursor cur = wp.cursors[gwave];
+        cur.s = __builtin_amdgcn_readfirstlane(cur.s);
+        cur.p = __builtin_amdgcn_readfirstlane(cur.p);
+        cur.off = __builtin_amdgcn_readfirstlane(cur.off);
+        // first sample of the wave's next block of 64
+        uint32_t s1 = cur.s + wp.stride_s, p1 = cur.p + wp.stride_p;
+        if (p1 >= n_pixels) {
+            p1 -= n_pixels;
+            s1 += 1;
+        }
+        const uint32_t o = cur.off + lane_rank(vacant_mask);
+        uint32_t s = o < 64u ? cur.s : s1;
+        uint32_t p = o < 64u ? cur.p + o : p1 + (o - 64u);
+        while (p >= n_pixels) {  // more than once only for images smaller than a wave
+            p -= n_pixels;
+            s += 1;
+        }
+        start = vacant && s < rp.n_samples;
+        // sample numbers grow with the lane rank, so the started lanes are a prefix of the vacant ones
+        const uint32_t taken = (uint32_t)__popcll(__ballot(start));
+        if (start) {
+            pixel = p;
+            sampler_start(path.smp, rp, pixel_key(rp.seed_lo, rp.seed_hi, pixel), rp.sample_begin + s);
+        }
+        if (taken && lane == 0) {
+            uint32_t off = cur.off + taken;
+            if (off >= 64u) {
+                cur.s = s1;
+                cur.p = p1;
+                off -= 64u;
+            }
+            cur.off = off;
+            wp.cursors[gwave] = cur;
+        }
+    }
+
+    // -- one 2D draw for every lane that needs one, then the new ray
+    R u2 = R(0), v2 = R(0);
+    if (start || mode == MAT_LAMBERTIAN || mode == MAT_PHONG) get_2d<R>(path.smp, rp, u2, v2);
+    bool have_ray = false;
+    if (start) {
+        const uint32_t py = pixel / rp.width;
+        const R px_c = (R)(pixel - py * rp.width) + R(0.5);
+        const R py_c = (R)py + R(0.5);
+        const R u = (px_c + u2) * rp.inv_width;  // src/renderer.rs:120-121
+        const R v = R(1) - (py_c + v2) * rp.inv_height;
+        path.o = mk<R>(sv.cam_o[0], sv.cam_o[1], sv.cam_o[2]);
+        path.d = camera_dir<R>(sv, u, v);
+        path.beta = mk<R>(1, 1, 1);
+        path.depth = 0;
+        have_ray = true;
+    } else if (mode != MODE_NEW) {
+        have_ray = scatter<R>(rp, path, mode, n, m, u2, v2);
+    }
+
+    // -- compaction
+    const unsigned long long ray_mask = __ballot(have_ray);
+    const uint32_t c_start = (uint32_t)__popcll(__ballot(start));
+    const uint32_t c_bad = (uint32_t)__popcll(__ballot(bad));
+    if (lane == 0) {
+        s_wave_rays[wave] = (uint32_t)__popcll(ray_mask);
+        if (c_start) atomicAdd(&s_ctr.v[COUNTER_SAMPLES], c_start);
+        if (c_bad) atomicAdd(&s_ctr.v[COUNTER_NONFINITE], c_bad);
+    }
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+        const uint32_t c = (uint32_t)__popcll(__ballot(counted == k));
+        if (lane == 0 && c) atomicAdd(&s_ctr.v[COUNTER_BOUNCE0 + k], c);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < WAVES; ++w) total += s_wave_rays[w];
+        s_base = total ? atomicAdd(&wp.ctl->count[parity ^ 1], total) : 0u;
+    }
+    __syncthreads();
+    if (have_ray) {
+        uint32_t slot = s_base + lane_rank(ray_mask);
+        for (uint32_t w = 0; w < wave; ++w) slot += s_wave_rays[w];
+        qo.o_dx[slot] = make_float4(path.o.x, path.o.y, path.o.z, path.d.x);
+        qo.dyz[slot] = make_float2(path.d.y, path.d.z);
+        qo.beta_pix[slot] = make_float4(path.beta.x, path.beta.y, path.beta.z, __uint_as_float(pixel));
+        qo.smp[slot] = make_uint2(path.smp.sample, path.smp.ctr | (path.smp.dim << 20) | (path.depth << 23));
+    }
+    counters_flush(s_ctr, wp.block_counters);
+}
+
+// ------------------------------------------------------------------ launchers
+hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_init, dim3((wp.capacity + 255u) / 256u), dim3(256), 0, stream, rp, wp);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity,
+                                 hipStream_t stream) {
+    const dim3 grid(wp.capacity / (uint32_t)WF_HIT_BLOCK), block(WF_HIT_BLOCK);
+    if (bvh)
+        hipLaunchKernelGGL(wf_closest_hit<true>, grid, block, 0, stream, sv, wp, parity);
+    else
+        hipLaunchKernelGGL(wf_closest_hit<false>, grid, block, 0, stream, sv, wp, parity);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_shade(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp, int parity,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(wf_shade, dim3(wp.capacity / (uint32_t)WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, stream, sv,
+                       rp, wp, parity);
+    return hipGetLastError();
+}
+
+}  // namespace rrt

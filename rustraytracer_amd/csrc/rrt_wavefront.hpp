@@ -1,0 +1,62 @@
+// Wavefront path tracer: path state lives in HBM queues between per-bounce kernels.
+//
+// One trip handles every live path once:
+//   wf_closest_hit   ray queue -> hit queue            (Scene::intersect, src/scene.rs:35-47)
+//   wf_shade         ray + hit queue -> next ray queue (src/tracers/utils.rs:41-87, one loop body)
+// wf_shade also starts new camera samples in every lane that has no surviving path, so the queue
+// stays full until the render runs out of samples, and writes survivors and new paths densely
+// (wave64 ballot + lane rank inside a wave, one counter reservation per block).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rrt_types.hpp"
+
+namespace rrt {
+
+// Structure-of-arrays queue of `capacity` paths.  A path takes 56 bytes; the closest-hit kernel
+// touches 24 (read) + 8 (write) of them.
+struct WfQueue {
+    float4* o_dx;      // ray origin xyz, direction x
+    float2* dyz;       // direction y, z
+    float2* hit;       // t, scan-order primitive index as int bits (WF_MISS, WF_EMPTY)
+    float4* beta_pix;  // throughput rgb, pixel index as uint bits
+    uint2* smp;        // sample index inside the pixel; draws | dimension << 20 | depth << 23
+};
+
+enum : int { WF_MISS = -1, WF_EMPTY = -2 };
+constexpr uint32_t WF_MAX_DEPTH = 511;  // 9 bits of the packed sampler word
+
+struct WfControl {
+    uint32_t count[2];        // live paths in queue 0 / 1
+    uint32_t pad[2];
+    unsigned long long rays;  // closest-hit queries so far
+};
+
+// Where a wave takes its next camera samples from.  Sample n of the render (n = s * n_pixels +
+// pixel: sample-major, so neighbouring lanes get neighbouring pixels) belongs to wave
+// (n / 64) % n_waves; a wave walks its own blocks of 64 in order, so no counter is shared.
+struct WfWaveCursor {
+    uint32_t s, p;  // sample index and pixel of the first sample of the current block
+    uint32_t off;   // samples of the current block already started
+    uint32_t pad;
+};
+
+struct WfParams {
+    WfQueue q[2];
+    WfControl* ctl;
+    WfWaveCursor* cursors;              // capacity / 64
+    unsigned long long* block_counters; // rows of COUNTER_COUNT, one per block of the widest launch
+    uint32_t capacity;                  // paths per queue, a multiple of the shade block size
+    uint32_t stride_s, stride_p;        // (64 * n_waves) / n_pixels and % n_pixels
+    uint32_t pad;
+};
+
+constexpr int WF_SHADE_BLOCK = 1024;
+constexpr int WF_HIT_BLOCK = 256;
+
+hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_t stream);
+hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity, hipStream_t stream);
+hipError_t wf_launch_shade(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp, int parity,
+                           hipStream_t stream);
+
+}  // namespace rrt
