@@ -150,7 +150,8 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # RRT_HIP_LIBRARY: another build of the same library (kernel experiments)
+    p = path or os.environ.get("RRT_HIP_LIBRARY") or LIB_PATH
     if not os.path.exists(p):
         raise BackendMissing(
             f"HIP backend library not found at {p}; run `python -c 'import __graft_entry__ as g; g.build()'` "

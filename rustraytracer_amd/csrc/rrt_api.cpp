@@ -294,6 +294,8 @@ struct DevBuf {
 
 // Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO.
 const size_t kAutoBvhThreshold = 48;
+// Subtrees of at most this many primitives are folded into one leaf.
+const int kBvhLeafMax = 4;
 
 float round_down(double x) {
     float f = (float)x;
@@ -342,12 +344,14 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
         }
         bounded.push_back((int32_t)g);
     }
+    if (bounded.size() > (size_t)rrt::BVH_MAX_PRIMS)
+        return fail(RRT_ERR_UNSUPPORTED, "the LBVH addresses at most %d bounded primitives", rrt::BVH_MAX_PRIMS);
     const int n = (int)bounded.size();
     int rc;
     const int32_t* d_lin = nullptr;
     if ((rc = upload(ds, unbounded, &d_lin, be->stream)) != RRT_OK) return rc;
     const int32_t* d_slot = nullptr;
-    const rrt::BvhNode* d_nodes = nullptr;
+    const rrt::WideNode* d_nodes = nullptr;
     if (n == 1) {
         if ((rc = upload(ds, bounded, &d_slot, be->stream)) != RRT_OK) return rc;
     } else if (n >= 2) {
@@ -357,13 +361,15 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
         HIP_TRY(hipMemcpyAsync(dlo.p, lo.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
         HIP_TRY(hipMemcpyAsync(dhi.p, hi.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
         void *nodes = nullptr, *slots = nullptr;
-        HIP_TRY(hipMalloc(&nodes, sizeof(rrt::BvhNode) * (size_t)(n - 1)));
+        HIP_TRY(hipMalloc(&nodes, sizeof(rrt::WideNode) * (size_t)(n - 1)));
         ds->allocs.push_back(nodes);
         HIP_TRY(hipMalloc(&slots, sizeof(int32_t) * (size_t)n));
         ds->allocs.push_back(slots);
         float flo[3], fhi[3];
         for (int k = 0; k < 3; ++k) { flo[k] = round_down(slo[k]); fhi[k] = round_up(shi[k]); }
-        HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, (rrt::BvhNode*)nodes,
+        int leaf_max = kBvhLeafMax;
+        if (const char* e = getenv("RRT_DEBUG_LEAF_MAX")) leaf_max = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : leaf_max;  // experiments
+        HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, leaf_max, (rrt::WideNode*)nodes,
                                 (int*)slots, be->stream));
         // sorted slot -> index among the bounded primitives -> scan-order index
         std::vector<int32_t> map((size_t)n);
@@ -373,8 +379,19 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
             map[i] = bounded[(size_t)map[i]];
         }
         HIP_TRY(hipMemcpy(slots, map.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-        d_nodes = (const rrt::BvhNode*)nodes;
+        d_nodes = (const rrt::WideNode*)nodes;
         d_slot = (const int32_t*)slots;
+    }
+    if (n >= 1) {  // leaf records in sorted-slot order, both precisions
+        void *l32 = nullptr, *l64 = nullptr;
+        HIP_TRY(hipMalloc(&l32, sizeof(rrt::LeafRec<float>) * (size_t)n));
+        ds->allocs.push_back(l32);
+        HIP_TRY(hipMalloc(&l64, sizeof(rrt::LeafRec<double>) * (size_t)n));
+        ds->allocs.push_back(l64);
+        HIP_TRY(rrt::lbvh_pack_leaves(ds->v32.prims, d_slot, n, (rrt::LeafRec<float>*)l32, be->stream));
+        HIP_TRY(rrt::lbvh_pack_leaves(ds->v64.prims, d_slot, n, (rrt::LeafRec<double>*)l64, be->stream));
+        ds->v32.leaves = (const rrt::LeafRec<float>*)l32;
+        ds->v64.leaves = (const rrt::LeafRec<double>*)l64;
     }
     HIP_TRY(hipStreamSynchronize(be->stream));
     ds->v32.nodes = ds->v64.nodes = d_nodes;
@@ -595,7 +612,7 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
     for (uint64_t trip = 0;; ++trip) {
         HIP_TRY(rrt::wf_launch_shade(sv, rp, wp, parity, be->stream));
         parity ^= 1;
-        HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, be->stream));
+        HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, be->n_cu * 8, be->stream));
         if (trip >= sure && (trip - sure) % check_every == 0) {
             HIP_TRY(hipMemcpyAsync(&ctl, wp.ctl, sizeof(ctl), hipMemcpyDeviceToHost, be->stream));
             HIP_TRY(hipStreamSynchronize(be->stream));

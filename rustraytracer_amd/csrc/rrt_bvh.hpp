@@ -41,83 +41,218 @@ RRT_DEV int hit_winner(const HitAcc<R>& h) {
     return h.last_incl > h.first ? h.last_incl : h.first;
 }
 
-// Ray/box slab test for the two children of a node.  Conservative: boxes are padded on the host and
-// the exit distance is widened by a few ulps, so the only effect of rounding is an extra visit.
+// Traversal stack of node links: the first BVH_LDS_LEVELS entries of every lane live in LDS
+// ([level][thread], so the 64 lanes of a wave hit 64 different banks), deeper entries in a private
+// spill array that a well-formed tree rarely reaches (a divergent private-memory access costs as
+// much as a divergent global one).  A 4-wide node pushes at most three entries per level, and the
+// binary radix tree under it (63-bit codes + 32-bit position tie-break) is at most 95 levels deep,
+// i.e. 48 wide levels.  Entries carry no distance: a stale entry costs one node fetch whose children
+// all fail, which happens for ~5 % of the nodes, and half the bytes per entry keep twice as many
+// levels in LDS at full occupancy.
+constexpr int BVH_LDS_LEVELS = 16;
+constexpr int BVH_SPILL_LEVELS = 3 * 48 - BVH_LDS_LEVELS;
+constexpr int BVH_BLOCK = 256;  // every kernel that traverses the tree runs 256-thread blocks
+constexpr int BVH_DONE = BVH_NO_CHILD;
+
+struct TreeStackLds {
+    int node[BVH_LDS_LEVELS][BVH_BLOCK];
+};
+// The private part of the stack is a separate local array in every kernel (a struct with a
+// dynamically indexed member would live in private memory as a whole).
+typedef int TreeStackSpill[BVH_SPILL_LEVELS];
+
+// Per-lane traversal state.  node >= 0: a wide node to fetch; BVH_DONE: nothing left;
+// any other negative value: a leaf to test.
 template <typename R>
-RRT_DEV void slab2(const BvhNode& N, V3<R> o, V3<R> inv_d, R t_best, bool& hit0, bool& hit1, R& near0, R& near1) {
-    const R widen = sizeof(R) == 4 ? R(1.0000004) : R(1.0000000001);
-    R ax = ((R)N.lo0[0] - o.x) * inv_d.x, bx = ((R)N.hi0[0] - o.x) * inv_d.x;
-    R ay = ((R)N.lo0[1] - o.y) * inv_d.y, by = ((R)N.hi0[1] - o.y) * inv_d.y;
-    R az = ((R)N.lo0[2] - o.z) * inv_d.z, bz = ((R)N.hi0[2] - o.z) * inv_d.z;
-    R en = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-    R ex = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz)) * widen;
-    hit0 = en <= ex && ex >= R(0) && en <= t_best;
-    near0 = en;
-    ax = ((R)N.lo1[0] - o.x) * inv_d.x; bx = ((R)N.hi1[0] - o.x) * inv_d.x;
-    ay = ((R)N.lo1[1] - o.y) * inv_d.y; by = ((R)N.hi1[1] - o.y) * inv_d.y;
-    az = ((R)N.lo1[2] - o.z) * inv_d.z; bz = ((R)N.hi1[2] - o.z) * inv_d.z;
-    en = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-    ex = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz)) * widen;
-    hit1 = en <= ex && ex >= R(0) && en <= t_best;
-    near1 = en;
+struct TreeWalk {
+    V3<R> o, d, inv_d;
+    HitAcc<R> acc;
+    int node;
+    int sp;
+};
+
+template <typename R>
+RRT_DEV void walk_start(TreeWalk<R>& w, V3<R> o, V3<R> d) {
+    w.o = o;
+    w.d = d;
+    // 1/d with the sign of d kept for zero components: +-inf slabs work with min/max that drop NaN
+    w.inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+    w.sp = 0;
+    w.node = 0;
 }
 
-constexpr int BVH_STACK = 64;  // a radix tree over 64-bit keys is at most 64 levels deep
-
-// Scene::intersect through the tree (plus a scan of the primitives kept out of it).
 template <typename R>
-RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, HitCounters& hc) {
-    HitAcc<R> acc;
-    hit_init(acc);
+RRT_DEV void walk_push(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, int node) {
+    if (w.sp < BVH_LDS_LEVELS) lds.node[w.sp][threadIdx.x] = node;
+    else if (w.sp < BVH_LDS_LEVELS + BVH_SPILL_LEVELS) spill[w.sp - BVH_LDS_LEVELS] = node;
+    w.sp += 1;
+}
+
+template <typename R>
+RRT_DEV void walk_pop(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill) {
+    if (w.sp == 0) {
+        w.node = BVH_DONE;
+        return;
+    }
+    w.sp -= 1;
+    w.node = w.sp < BVH_LDS_LEVELS ? lds.node[w.sp][threadIdx.x] : spill[w.sp - BVH_LDS_LEVELS];
+}
+
+template <typename R>
+RRT_DEV void order2(R& da, int& ca, R& db, int& cb) {
+    const bool swap = db < da;
+    const R d0 = swap ? db : da, d1 = swap ? da : db;
+    const int c0 = swap ? cb : ca, c1 = swap ? ca : cb;
+    da = d0; db = d1; ca = c0; cb = c1;
+}
+
+RRT_DEV float byte_to_float(uint32_t word, int k) {  // v_cvt_f32_ubyte<k>
+    return (float)((word >> (8 * k)) & 0xffu);
+}
+
+// One wide node, given as the four 16-byte words of its WideNode record: slab tests of its (up to)
+// four children, nearest child next, the others on the stack with the farthest deepest.
+// Conservative: boxes are padded on the host, quantised outward by the builder, and the exit
+// distance is widened by a few ulps, so the only effect of rounding is an extra visit.
+template <typename R>
+RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, uint4 q0, uint4 q1, uint4 q2, uint4 q3) {
+    const R widen = sizeof(R) == 4 ? R(1.0000004) : R(1.0000000001);
+    const R inf = Num<R>::tmax();
+    const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
+    const float sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23),
+                sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+    const uint32_t qlx = q1.x, qly = q1.y, qlz = q1.z, qhx = q1.w, qhy = q2.x, qhz = q2.y;
+    const int link[4] = {(int)q2.z, (int)q2.w, (int)q3.x, (int)q3.y};
+    R dist[4];
+    int child[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float lox = __builtin_fmaf(byte_to_float(qlx, k), sx, ox);
+        const float loy = __builtin_fmaf(byte_to_float(qly, k), sy, oy);
+        const float loz = __builtin_fmaf(byte_to_float(qlz, k), sz, oz);
+        const float hix = __builtin_fmaf(byte_to_float(qhx, k), sx, ox);
+        const float hiy = __builtin_fmaf(byte_to_float(qhy, k), sy, oy);
+        const float hiz = __builtin_fmaf(byte_to_float(qhz, k), sz, oz);
+        const R ax = ((R)lox - w.o.x) * w.inv_d.x, bx = ((R)hix - w.o.x) * w.inv_d.x;
+        const R ay = ((R)loy - w.o.y) * w.inv_d.y, by = ((R)hiy - w.o.y) * w.inv_d.y;
+        const R az = ((R)loz - w.o.z) * w.inv_d.z, bz = ((R)hiz - w.o.z) * w.inv_d.z;
+        const R en = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+        const R ex = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz)) * widen;
+        child[k] = link[k];
+        const bool hit = en <= ex && ex >= R(0) && en <= w.acc.t && child[k] != BVH_NO_CHILD;
+        dist[k] = hit ? en : inf;
+    }
+    // sorting network for four keys
+    order2(dist[0], child[0], dist[1], child[1]);
+    order2(dist[2], child[2], dist[3], child[3]);
+    order2(dist[0], child[0], dist[2], child[2]);
+    order2(dist[1], child[1], dist[3], child[3]);
+    order2(dist[1], child[1], dist[2], child[2]);
+    if (dist[3] < inf) walk_push(w, lds, spill, child[3]);
+    if (dist[2] < inf) walk_push(w, lds, spill, child[2]);
+    if (dist[1] < inf) walk_push(w, lds, spill, child[1]);
+    if (dist[0] < inf) w.node = child[0];
+    else walk_pop(w, lds, spill);
+}
+
+// One leaf primitive, given as the four 16-byte words of its LeafRec<float> record, against the ray.
+// Triangles and parallelograms are tested from these words with the arithmetic of prim_test_as, in
+// the same order (the scan and the tree must agree bit for bit); other types from their PrimRec.
+template <typename R>
+RRT_DEV void leaf_test_words(const SceneView<R>& sv, uint4 q0, uint4 q1, uint4 q2, uint4 q3, V3<R> o, V3<R> d,
+                             HitAcc<R>& acc) {
+    static_assert(sizeof(R) == 4, "leaf words are an f32 record");
+    const int type = (int)q3.x, g = (int)q3.y;
+    R t;
+    bool ok;
+    if (type == PRIM_TRIANGLE || type == PRIM_PGRAM) {
+        const R f0 = __uint_as_float(q0.x), f1 = __uint_as_float(q0.y), f2 = __uint_as_float(q0.z), f3 = __uint_as_float(q0.w);
+        const R f4 = __uint_as_float(q1.x), f5 = __uint_as_float(q1.y), f6 = __uint_as_float(q1.z), f7 = __uint_as_float(q1.w);
+        const R f8 = __uint_as_float(q2.x), f9 = __uint_as_float(q2.y), f10 = __uint_as_float(q2.z), f11 = __uint_as_float(q2.w);
+        const R best_t = Num<R>::tmax();
+        R nd = f0 * d.x + f1 * d.y + f2 * d.z;
+        R no = ((f3 - f0 * o.x) - f1 * o.y) - f2 * o.z;
+        t = no * Num<R>::rcp(nd);
+        V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
+        R a = f4 * P.x + (f5 * P.y + (f6 * P.z + f7));
+        R b = f8 * P.x + (f9 * P.y + (f10 * P.z + f11));
+        R det_ok = Num<R>::abs(nd) - Num<R>::eps();
+        if (type == PRIM_PGRAM) {
+            R h = min3(R(0.5) - Num<R>::abs(a), R(0.5) - Num<R>::abs(b), det_ok);
+            ok = min3(h, t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
+        } else {
+            R h = min3(min3(a, b, R(1) - a), R(1) - (a + b), det_ok);
+            ok = (h >= R(0)) && (fmin(t - Num<R>::tmin(), headroom(best_t, t)) > R(0));
+        }
+    } else {
+        ok = prim_test(as_constant(sv.prims) + g, o, d, Num<R>::tmax(), t);  // sphere, general quad
+    }
+    if (ok) hit_consider(acc, t, g, type != PRIM_TRIANGLE);
+}
+
+// One leaf primitive read through its record (any precision).
+template <typename R>
+RRT_DEV void leaf_test(const SceneView<R>& sv, const LeafRec<R>* leaf, V3<R> o, V3<R> d, HitAcc<R>& acc) {
+    const int type = leaf->type;
+    const int g = leaf->g;
+    const PrimRec<R> RRT_CONSTANT* as_prim = (const PrimRec<R> RRT_CONSTANT*)(const void*)leaf;
+    R t;
+    bool ok;
+    if (type == PRIM_TRIANGLE) {
+        ok = prim_test_as<R, PRIM_TRIANGLE>(as_prim, o, d, Num<R>::tmax(), t);  // reads f[0..11] only
+    } else if (type == PRIM_PGRAM) {
+        ok = prim_test_as<R, PRIM_PGRAM>(as_prim, o, d, Num<R>::tmax(), t);     // reads f[0..11] only
+    } else {
+        ok = prim_test(as_constant(sv.prims) + g, o, d, Num<R>::tmax(), t);     // sphere, general quad
+    }
+    if (ok) hit_consider(acc, t, g, type != PRIM_TRIANGLE);
+}
+
+// The primitives kept out of the tree (unbounded planes), scanned wave-uniformly.
+template <typename R>
+RRT_DEV void scan_beside_tree(const SceneView<R>& sv, V3<R> o, V3<R> d, HitAcc<R>& acc, HitCounters& hc) {
     const PrimRec<R> RRT_CONSTANT* prims = as_constant(sv.prims);
-    // unbounded primitives (planes): wave-uniform scan
     const int32_t RRT_CONSTANT* lin = as_constant(sv.linear_prim);
     for (int k = 0; k < sv.n_linear_prims; ++k) {
         const int g = lin[k];
         R t;
         if (prim_test(prims + g, o, d, Num<R>::tmax(), t)) hit_consider(acc, t, g, prims[g].type != PRIM_TRIANGLE);
-        hc.prim_tests += 1;
     }
+    hc.prim_tests += (uint32_t)sv.n_linear_prims;
+}
+
+// Scene::intersect through the tree (plus a scan of the primitives kept out of it): one ray per
+// lane from start to end (parity kernels and the fused renderer; the wavefront pipeline has a
+// persistent variant of this loop).
+template <typename R>
+RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, HitCounters& hc) {
+    __shared__ TreeStackLds s_stack;
+    TreeStackSpill spill;
+    TreeWalk<R> w;
+    hit_init(w.acc);
+    scan_beside_tree(sv, o, d, w.acc, hc);
     if (sv.n_bvh_prims == 1) {
-        const int g = sv.bvh_prim[0];
-        R t;
-        if (prim_test(prims + g, o, d, Num<R>::tmax(), t)) hit_consider(acc, t, g, prims[g].type != PRIM_TRIANGLE);
+        leaf_test<R>(sv, sv.leaves, o, d, w.acc);
         hc.prim_tests += 1;
     } else if (sv.n_bvh_prims > 1) {
-        // 1/d with the sign of d kept for zero components: +-inf slabs work with min/max that drop NaN
-        V3<R> inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
-        int stack[BVH_STACK];
-        int sp = 0;
-        int node = 0;
-        for (;;) {
-            if (node >= 0) {
-                const BvhNode N = sv.nodes[node];
-                bool h0, h1;
-                R n0, n1;
-                slab2<R>(N, o, inv_d, acc.t, h0, h1, n0, n1);
+        walk_start(w, o, d);
+        while (w.node != BVH_DONE) {
+            if (w.node >= 0) {
+                const uint4* rec = reinterpret_cast<const uint4*>(sv.nodes + w.node);
+                walk_node(w, s_stack, spill, rec[0], rec[1], rec[2], rec[3]);
                 hc.node_tests += 1;
-                if (h0 && h1) {
-                    const bool first0 = n0 <= n1;
-                    if (sp < BVH_STACK) stack[sp++] = first0 ? N.c1 : N.c0;
-                    node = first0 ? N.c0 : N.c1;
-                    continue;
-                }
-                if (h0 || h1) {
-                    node = h0 ? N.c0 : N.c1;
-                    continue;
-                }
             } else {
-                const int g = sv.bvh_prim[~node];
-                R t;
-                if (prim_test(prims + g, o, d, Num<R>::tmax(), t)) hit_consider(acc, t, g, prims[g].type != PRIM_TRIANGLE);
+                const int v = ~w.node;
+                const int slot = v & BVH_SLOT_MASK, left = v >> BVH_SLOT_BITS;
+                leaf_test<R>(sv, sv.leaves + slot, w.o, w.d, w.acc);
                 hc.prim_tests += 1;
+                if (left > 0) w.node = ~((slot + 1) | ((left - 1) << BVH_SLOT_BITS));
+                else walk_pop(w, s_stack, spill);
             }
-            if (sp == 0) break;
-            node = stack[--sp];
         }
     }
-    t_out = acc.t;
-    return hit_winner(acc);
+    t_out = w.acc.t;
+    return hit_winner(w.acc);
 }
 
 // Closest hit over the whole scene.  Returns the scan-order primitive index or -1.

@@ -1,13 +1,16 @@
 // GPU construction of a linear BVH (LBVH) over the bounded primitives of a scene.
 //
 //   1. host: f64 bounds of every primitive, rounded outward to f32 and padded (rrt_api.cpp)
-//   2. morton_kernel   30-bit Morton code of the box centre | sorted position tie-break -> unique 64-bit keys
-//   3. rocPRIM radix sort of the keys (the primitive slot rides in the low 32 bits)
+//   2. morton_kernel   63-bit Morton code of the box centre (21 bits per axis)
+//   3. rocPRIM radix sort of (code, primitive) pairs; equal codes are ordered by sorted position
 //   4. hierarchy_kernel Karras' parallel binary radix tree: one thread per internal node
 //   5. refit_kernel    bottom-up AABB fit, one thread per leaf, second arrival at a node continues
 //
-// Node layout: an internal node holds the boxes of BOTH children, so one 64-byte fetch decides both
-// descents.  child < 0 encodes a leaf: ~child = sorted slot; prim_of_slot[slot] = scan-order primitive.
+//   6. collapse_kernel subtrees of a few primitives become single leaves (slot ranges)
+//   7. widen_kernel    every binary node with its children expanded: the 4-wide nodes rays traverse
+//
+// A binary node holds the boxes of BOTH children; child < 0 encodes a leaf, see BvhNode;
+// prim_of_slot[slot] = index into the bounds arrays.
 #include <hip/hip_runtime.h>
 
 #include <cstring>  // rocPRIM uses ::memset in host code without including it
@@ -18,39 +21,48 @@
 
 namespace rrt {
 
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+// 21 bits -> every third bit of 63
+__device__ __forceinline__ unsigned long long expand_bits21(unsigned long long x) {
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
 }
 
 __global__ void __launch_bounds__(256)
 morton_kernel(const float* __restrict__ lo, const float* __restrict__ hi, int n, float3 scene_lo, float3 inv_extent,
-              unsigned long long* __restrict__ keys) {
+              unsigned long long* __restrict__ keys, unsigned int* __restrict__ index) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float cx = 0.5f * (lo[3 * i] + hi[3 * i]), cy = 0.5f * (lo[3 * i + 1] + hi[3 * i + 1]),
           cz = 0.5f * (lo[3 * i + 2] + hi[3 * i + 2]);
-    float nx = fminf(fmaxf((cx - scene_lo.x) * inv_extent.x * 1024.f, 0.f), 1023.f);
-    float ny = fminf(fmaxf((cy - scene_lo.y) * inv_extent.y * 1024.f, 0.f), 1023.f);
-    float nz = fminf(fmaxf((cz - scene_lo.z) * inv_extent.z * 1024.f, 0.f), 1023.f);
-    uint32_t code = (expand_bits10((uint32_t)nx) << 2) | (expand_bits10((uint32_t)ny) << 1) | expand_bits10((uint32_t)nz);
-    keys[i] = ((unsigned long long)code << 32) | (uint32_t)i;  // unique: equal codes are split by the index
+    const float cells = 2097152.f;  // 2^21 per axis
+    float nx = fminf(fmaxf((cx - scene_lo.x) * inv_extent.x * cells, 0.f), cells - 1.f);
+    float ny = fminf(fmaxf((cy - scene_lo.y) * inv_extent.y * cells, 0.f), cells - 1.f);
+    float nz = fminf(fmaxf((cz - scene_lo.z) * inv_extent.z * cells, 0.f), cells - 1.f);
+    keys[i] = (expand_bits21((unsigned long long)nx) << 2) | (expand_bits21((unsigned long long)ny) << 1) |
+              expand_bits21((unsigned long long)nz);
+    index[i] = (unsigned int)i;
 }
 
+// Length of the common prefix of sorted keys i and j; equal codes are told apart by the position
+// itself (Karras 2012, section 4), so the tree is well defined for any input.
 __device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    return __clzll((long long)(keys[i] ^ keys[j]));
+    unsigned long long x = keys[i] ^ keys[j];
+    return x ? __clzll((long long)x) : 64 + __clz(i ^ j);
 }
 
 // Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees" (2012), fig. 4.
+// Also records the range of sorted slots under every internal node.
 __global__ void __launch_bounds__(256)
 hierarchy_kernel(const unsigned long long* __restrict__ keys, int n, BvhNode* __restrict__ nodes,
-                 int* __restrict__ node_parent, int* __restrict__ leaf_parent, int* __restrict__ prim_of_slot) {
+                 int* __restrict__ node_parent, int* __restrict__ leaf_parent, int* __restrict__ range_first,
+                 int* __restrict__ range_count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) prim_of_slot[i] = (int)(uint32_t)keys[i];
     if (i >= n - 1) return;
     int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
     int dmin = delta(keys, n, i, i - d);
@@ -72,9 +84,102 @@ hierarchy_kernel(const unsigned long long* __restrict__ keys, int n, BvhNode* __
     int right = hi_i == gamma + 1 ? ~(gamma + 1) : gamma + 1;
     nodes[i].c0 = left;
     nodes[i].c1 = right;
+    range_first[i] = lo_i;
+    range_count[i] = hi_i - lo_i + 1;
     if (left < 0) leaf_parent[~left] = i; else node_parent[left] = i;
     if (right < 0) leaf_parent[~right] = i; else node_parent[right] = i;
     if (i == 0) node_parent[0] = -1;
+}
+
+// Folds every subtree of at most leaf_max primitives into one leaf of its parent: the child link
+// becomes the subtree's slot range, the child box (already the union of the subtree) stays.
+__global__ void __launch_bounds__(256)
+collapse_kernel(BvhNode* __restrict__ nodes, int n, const int* __restrict__ range_first,
+                const int* __restrict__ range_count, int leaf_max) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int c0 = nodes[i].c0, c1 = nodes[i].c1;
+    if (c0 >= 0 && range_count[c0] <= leaf_max) nodes[i].c0 = ~(range_first[c0] | ((range_count[c0] - 1) << BVH_SLOT_BITS));
+    if (c1 >= 0 && range_count[c1] <= leaf_max) nodes[i].c1 = ~(range_first[c1] | ((range_count[c1] - 1) << BVH_SLOT_BITS));
+}
+
+// Wide node i = binary node i with both children expanded, boxes quantised (see WideNode).
+__global__ void __launch_bounds__(256) widen_kernel(const BvhNode* __restrict__ nodes, int n, WideNode* __restrict__ wide) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const BvhNode N = nodes[i];
+    float lo[4][3], hi[4][3];
+    int child[4];
+    int k = 0;
+    auto put = [&](const float* l, const float* h, int c) {
+        for (int a = 0; a < 3; ++a) { lo[k][a] = l[a]; hi[k][a] = h[a]; }
+        child[k] = c;
+        ++k;
+    };
+    if (N.c0 >= 0) {
+        const BvhNode C = nodes[N.c0];
+        put(C.lo0, C.hi0, C.c0);
+        put(C.lo1, C.hi1, C.c1);
+    } else {
+        put(N.lo0, N.hi0, N.c0);
+    }
+    if (N.c1 >= 0) {
+        const BvhNode C = nodes[N.c1];
+        put(C.lo0, C.hi0, C.c0);
+        put(C.lo1, C.hi1, C.c1);
+    } else {
+        put(N.lo1, N.hi1, N.c1);
+    }
+    const int used = k;
+    WideNode W;
+    W.pad0 = 0;
+    W.pad1[0] = W.pad1[1] = 0;
+    for (int a = 0; a < 3; ++a) {
+        float org = lo[0][a], top = hi[0][a];
+        for (int c = 1; c < used; ++c) { org = fminf(org, lo[c][a]); top = fmaxf(top, hi[c][a]); }
+        // smallest power of two s with org + 255 s >= top, in the traversal's own arithmetic
+        int ex;
+        (void)frexpf(fmaxf(top - org, 1e-30f) / 255.f, &ex);  // value = m 2^ex, m in [0.5, 1)
+        int e = ex + 127;                                      // biased exponent of 2^ex >= value
+        e = e < 1 ? 1 : (e > 254 ? 254 : e);
+        while (e < 254 && fmaf(255.f, __uint_as_float((uint32_t)e << 23), org) < top) ++e;
+        const float s = __uint_as_float((uint32_t)e << 23);
+        uint32_t wlo = 0, whi = 0;
+        for (int c = 0; c < 4; ++c) {
+            int ql = 0, qh = 0;  // an empty slot decodes to a point box; its NO_CHILD link is what rejects it
+            if (c < used) {
+                ql = (int)floorf((lo[c][a] - org) / s);
+                ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+                while (ql > 0 && fmaf((float)ql, s, org) > lo[c][a]) --ql;
+                qh = (int)ceilf((hi[c][a] - org) / s);
+                qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+                while (qh < 255 && fmaf((float)qh, s, org) < hi[c][a]) ++qh;
+            }
+            wlo |= (uint32_t)ql << (8 * c);
+            whi |= (uint32_t)qh << (8 * c);
+        }
+        W.org[a] = org;
+        W.e[a] = (uint8_t)e;
+        W.qlo[a] = wlo;
+        W.qhi[a] = whi;
+    }
+    for (int c = 0; c < 4; ++c) W.child[c] = c < used ? child[c] : BVH_NO_CHILD;
+    wide[i] = W;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256)
+pack_leaves_kernel(const PrimRec<R>* __restrict__ prims, const int* __restrict__ prim_of_slot, int n,
+                   LeafRec<R>* __restrict__ out) {
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int g = prim_of_slot[s];
+    LeafRec<R> r;
+    for (int k = 0; k < 12; ++k) r.f[k] = prims[g].f[k];
+    r.type = prims[g].type;
+    r.g = g;
+    r.pad[0] = r.pad[1] = 0;
+    out[s] = r;
 }
 
 __global__ void __launch_bounds__(256)
@@ -113,44 +218,74 @@ refit_kernel(const float* __restrict__ lo, const float* __restrict__ hi, const i
 }
 
 hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float scene_lo[3], const float scene_hi[3],
-                      BvhNode* d_nodes, int* d_prim_of_slot, hipStream_t stream) {
-    if (n < 2) return hipErrorInvalidValue;
+                      int leaf_max, WideNode* d_wide, int* d_prim_of_slot, hipStream_t stream) {
+    if (n < 2 || n > BVH_MAX_PRIMS || leaf_max < 1 || leaf_max > 8) return hipErrorInvalidValue;
     hipError_t e;
+    BvhNode* d_nodes = nullptr;
     unsigned long long *keys_in = nullptr, *keys_out = nullptr;
-    int *node_parent = nullptr, *leaf_parent = nullptr;
+    unsigned int* index_in = nullptr;
+    int *node_parent = nullptr, *leaf_parent = nullptr, *range_first = nullptr, *range_count = nullptr;
     unsigned int* flags = nullptr;
     void* temp = nullptr;
     size_t temp_bytes = 0;
     auto cleanup = [&]() {
-        (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(node_parent); (void)hipFree(leaf_parent);
-        (void)hipFree(flags); (void)hipFree(temp);
+        (void)hipFree(d_nodes);
+        (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(index_in); (void)hipFree(node_parent);
+        (void)hipFree(leaf_parent); (void)hipFree(range_first); (void)hipFree(range_count); (void)hipFree(flags);
+        (void)hipFree(temp);
     };
 #define LBVH_TRY(x) do { e = (x); if (e != hipSuccess) { cleanup(); return e; } } while (0)
+    LBVH_TRY(hipMalloc(&d_nodes, sizeof(BvhNode) * (size_t)(n - 1)));
     LBVH_TRY(hipMalloc(&keys_in, sizeof(unsigned long long) * n));
     LBVH_TRY(hipMalloc(&keys_out, sizeof(unsigned long long) * n));
+    LBVH_TRY(hipMalloc(&index_in, sizeof(unsigned int) * n));
     LBVH_TRY(hipMalloc(&node_parent, sizeof(int) * n));
     LBVH_TRY(hipMalloc(&leaf_parent, sizeof(int) * n));
+    LBVH_TRY(hipMalloc(&range_first, sizeof(int) * n));
+    LBVH_TRY(hipMalloc(&range_count, sizeof(int) * n));
     LBVH_TRY(hipMalloc(&flags, sizeof(unsigned int) * n));
     LBVH_TRY(hipMemsetAsync(flags, 0, sizeof(unsigned int) * n, stream));
     float3 slo = make_float3(scene_lo[0], scene_lo[1], scene_lo[2]);
     auto inv = [](float a, float b) { return b > a ? 1.0f / (b - a) : 0.0f; };
     float3 iext = make_float3(inv(scene_lo[0], scene_hi[0]), inv(scene_lo[1], scene_hi[1]), inv(scene_lo[2], scene_hi[2]));
     dim3 block(256), grid((n + 255) / 256);
-    hipLaunchKernelGGL(morton_kernel, grid, block, 0, stream, d_lo, d_hi, n, slo, iext, keys_in);
+    hipLaunchKernelGGL(morton_kernel, grid, block, 0, stream, d_lo, d_hi, n, slo, iext, keys_in, index_in);
     LBVH_TRY(hipGetLastError());
-    LBVH_TRY(rocprim::radix_sort_keys(nullptr, temp_bytes, keys_in, keys_out, (size_t)n, 0, 64, stream));
+    unsigned int* index_out = reinterpret_cast<unsigned int*>(d_prim_of_slot);
+    LBVH_TRY(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in, keys_out, index_in, index_out, (size_t)n, 0, 63,
+                                       stream));
     LBVH_TRY(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
-    LBVH_TRY(rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t)n, 0, 64, stream));
+    LBVH_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, index_in, index_out, (size_t)n, 0, 63,
+                                       stream));
     hipLaunchKernelGGL(hierarchy_kernel, grid, block, 0, stream, keys_out, n, d_nodes, node_parent, leaf_parent,
-                       d_prim_of_slot);
+                       range_first, range_count);
     LBVH_TRY(hipGetLastError());
     hipLaunchKernelGGL(refit_kernel, grid, block, 0, stream, d_lo, d_hi, d_prim_of_slot, n, d_nodes, node_parent,
                        leaf_parent, flags);
+    LBVH_TRY(hipGetLastError());
+    if (leaf_max > 1) {
+        hipLaunchKernelGGL(collapse_kernel, grid, block, 0, stream, d_nodes, n, range_first, range_count, leaf_max);
+        LBVH_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(widen_kernel, grid, block, 0, stream, d_nodes, n, d_wide);
     LBVH_TRY(hipGetLastError());
     LBVH_TRY(hipStreamSynchronize(stream));
 #undef LBVH_TRY
     cleanup();
     return hipSuccess;
+}
+
+template <typename R>
+static hipError_t pack_leaves_t(const PrimRec<R>* prims, const int* prim_of_slot, int n, LeafRec<R>* out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_leaves_kernel<R>, dim3((n + 255) / 256), dim3(256), 0, stream, prims, prim_of_slot, n, out);
+    return hipGetLastError();
+}
+hipError_t lbvh_pack_leaves(const PrimRec<float>* prims, const int* prim_of_slot, int n, LeafRec<float>* out, hipStream_t s) {
+    return pack_leaves_t<float>(prims, prim_of_slot, n, out, s);
+}
+hipError_t lbvh_pack_leaves(const PrimRec<double>* prims, const int* prim_of_slot, int n, LeafRec<double>* out, hipStream_t s) {
+    return pack_leaves_t<double>(prims, prim_of_slot, n, out, s);
 }
 
 }  // namespace rrt

@@ -7,9 +7,14 @@
 namespace rrt {
 
 // d_lo / d_hi: n x 3 f32 primitive bounds on the device (already conservative);
-// d_nodes: n - 1 nodes (node 0 is the root); d_prim_of_slot: n entries, sorted slot -> index into
+// d_wide: n - 1 wide nodes (node 0 is the root); d_prim_of_slot: n entries, sorted slot -> index into
 // the bounds arrays.  Needs n >= 2.  Synchronises the stream.
+// leaf_max (1..8): subtrees of at most this many primitives become one leaf.
 hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float scene_lo[3], const float scene_hi[3],
-                      BvhNode* d_nodes, int* d_prim_of_slot, hipStream_t stream);
+                      int leaf_max, WideNode* d_wide, int* d_prim_of_slot, hipStream_t stream);
+
+// out[slot] = leaf record of primitive prim_of_slot[slot] (scan-order indices), n entries.
+hipError_t lbvh_pack_leaves(const PrimRec<float>* prims, const int* prim_of_slot, int n, LeafRec<float>* out, hipStream_t s);
+hipError_t lbvh_pack_leaves(const PrimRec<double>* prims, const int* prim_of_slot, int n, LeafRec<double>* out, hipStream_t s);
 
 }  // namespace rrt

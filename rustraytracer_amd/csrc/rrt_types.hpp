@@ -67,10 +67,15 @@ struct MatRec {
     int32_t pad[2];
 };
 
-// LBVH node (rrt_lbvh.hip): the boxes of both children and the child links.  child < 0 encodes a
-// leaf: ~child = sorted slot.  Boxes are f32, rounded outward and padded on the host, so a slab
-// test never rejects a box whose primitive the ray test would accept.
-struct BvhNode {
+// Binary LBVH node as the builder makes it (rrt_lbvh.hip): the boxes of both children and the
+// child links.  child >= 0: internal node index.  child < 0: a leaf, ~child = first sorted slot |
+// (count - 1) << 28, i.e. 1..8 primitives that are neighbours in the sorted order (a subtree small
+// enough is folded into one leaf).  Boxes are f32, rounded outward and padded on the host, so a
+// slab test never rejects a box whose primitive the ray test would accept.
+constexpr int BVH_SLOT_BITS = 28;
+constexpr int BVH_SLOT_MASK = (1 << BVH_SLOT_BITS) - 1;
+constexpr int BVH_MAX_PRIMS = BVH_SLOT_MASK;  // so that ~child never equals INT_MIN
+struct alignas(64) BvhNode {
     float lo0[3];
     int32_t c0;
     float hi0[3];
@@ -79,6 +84,36 @@ struct BvhNode {
     int32_t pad0;
     float hi1[3];
     int32_t pad1;
+};
+
+// A primitive as tree leaves read it, in sorted-slot order: the first 12 numbers of its PrimRec
+// (all a triangle or parallelogram test reads), its record type and its scan-order index.  One
+// 64-byte line in f32.  Spheres and general quads are tested from their full PrimRec.
+template <typename R>
+struct alignas(sizeof(R) == 4 ? 64 : 128) LeafRec {
+    R f[12];
+    int32_t type;
+    int32_t g;
+    int32_t pad[2];
+};
+
+// What rays traverse: binary node i with its internal children expanded one level, i.e. up to four
+// grandchildren of i side by side (same child encoding, BVH_NO_CHILD pads a node that has fewer),
+// with the child boxes quantised to 8 bits per bound on a grid local to the node:
+//   bound = org[axis] + q * 2^(e[axis] - 127),   lower bounds rounded down, upper bounds up,
+// checked at build time against the very expression the traversal evaluates.  64 bytes: a divergent
+// fetch costs the texture-address unit per lane and per 16 bytes, so the traversal kernel's speed
+// is set by how few bytes a step needs, and 4-wide nodes halve the dependent fetches per ray.
+// Indexed like the binary nodes; node 0 is the root.
+constexpr int BVH_NO_CHILD = (int)0x80000000;
+struct alignas(64) WideNode {
+    float org[3];
+    uint8_t e[3];
+    uint8_t pad0;
+    uint32_t qlo[3];  // byte k of qlo[axis] = lower bound of child k
+    uint32_t qhi[3];
+    int32_t child[4];
+    int32_t pad1[2];
 };
 
 template <typename R>
@@ -97,8 +132,9 @@ struct SceneView {
     int32_t n_runs;
     int32_t pad0;
     // acceleration structure (n_bvh_prims == 0: linear scan over all prims)
-    const BvhNode* nodes;       // n_bvh_prims - 1 nodes, node 0 is the root
+    const WideNode* nodes;      // n_bvh_prims - 1 nodes, node 0 is the root
     const int32_t* bvh_prim;    // sorted slot -> scan-order primitive index
+    const LeafRec<R>* leaves;   // n_bvh_prims, sorted-slot order
     const int32_t* linear_prim; // primitives kept out of the tree (unbounded planes), scan order
     int32_t n_bvh_prims;
     int32_t n_linear_prims;

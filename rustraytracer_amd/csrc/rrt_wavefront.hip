@@ -1,6 +1,8 @@
 // Wavefront path tracer kernels for gfx950 (see rrt_wavefront.hpp for the queue layout).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rrt_bvh.hpp"
 #include "rrt_shade.hpp"
 #include "rrt_wavefront.hpp"
@@ -89,6 +91,108 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
         __syncthreads();
         counters_flush(s_ctr, wp.block_counters);
     }
+}
+
+// ------------------------------------------------------------------ closest hit through the tree
+// Tree traversal lengths differ by an order of magnitude between the rays of one wave (a ray that
+// only sees the room's walls is done after a few nodes, one that grazes a mesh visits hundreds), so
+// one-ray-per-lane leaves most lanes idle most of the time.  Here a wave is persistent: it walks its
+// own blocks of 64 rays (block b belongs to wave b % n_waves, no shared counter) and hands the next
+// rays to lanes as they finish, whenever at least WF_REFILL_MIN lanes are idle.
+constexpr int WF_REFILL_MIN = 12;
+
+__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
+wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min) {
+    typedef float R;
+    __shared__ TreeStackLds s_stack;
+    __shared__ BlockCounters s_ctr;
+    const uint32_t n_in = wp.ctl->count[parity];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wp.ctl->count[parity ^ 1] = 0;
+        wp.ctl->rays += n_in;
+    }
+    const uint32_t n_waves = gridDim.x * (BVH_BLOCK / 64);
+    uint32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (BVH_BLOCK / 64) + (threadIdx.x >> 6));
+    if (blockIdx.x * (uint32_t)BVH_BLOCK >= n_in) return;  // the block's first blocks of rays do not exist
+    if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t off = 0;
+    const WfQueue& q = wp.q[parity];
+
+    TreeStackSpill spill;
+    TreeWalk<R> w;
+    w.o = mk<R>(0, 0, 0);
+    w.d = w.inv_d = mk<R>(0, 0, 1);
+    hit_init(w.acc);
+    w.node = BVH_DONE;
+    w.sp = 0;
+    HitCounters hc{0, 0};
+    uint32_t mine = 0;
+    bool have = false;
+
+    for (;;) {
+        const bool idle = w.node == BVH_DONE;
+        const unsigned long long idle_mask = __ballot(idle);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (n_idle >= (uint32_t)refill_min || idle_mask == __ballot(true)) {
+            if (idle && have) {
+                const int g = hit_winner(w.acc);
+                q.hit[mine] = make_float2(w.acc.t, __int_as_float(g >= 0 ? g : WF_MISS));
+                have = false;
+            }
+            if ((unsigned long long)blk * 64ull < (unsigned long long)n_in) {
+                const uint32_t k = off + lane_rank(idle_mask);
+                const unsigned long long idx64 =
+                    k < 64u ? (unsigned long long)blk * 64ull + k : ((unsigned long long)blk + n_waves) * 64ull + (k - 64u);
+                if (idle && idx64 < (unsigned long long)n_in) {
+                    mine = (uint32_t)idx64;
+                    const float4 a = q.o_dx[mine];
+                    const float2 b = q.dyz[mine];
+                    hit_init(w.acc);
+                    walk_start(w, mk<R>(a.x, a.y, a.z), mk<R>(a.w, b.x, b.y));
+                    scan_beside_tree(sv, w.o, w.d, w.acc, hc);
+                    have = true;
+                }
+                off += n_idle;
+                if (off >= 64u) {
+                    off -= 64u;
+                    blk += n_waves;
+                }
+            }
+            if (__ballot(w.node != BVH_DONE) == 0ull) break;
+        }
+        // One step for every lane that has work: a wide node or ONE leaf primitive.  Both records are
+        // 64 bytes, so all lanes share the same four 16-byte loads and only the arithmetic diverges;
+        // no lane waits for the others to reach the same kind of record.
+        if (w.node != BVH_DONE) {
+            const bool at_node = w.node >= 0;
+            const int v = ~w.node;
+            const int slot = v & BVH_SLOT_MASK;
+            const uint4* rec = at_node ? reinterpret_cast<const uint4*>(sv.nodes + w.node)
+                                       : reinterpret_cast<const uint4*>(sv.leaves + slot);
+            const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+            if (at_node) {
+                walk_node(w, s_stack, spill, q0, q1, q2, q3);
+                hc.node_tests += 1;
+            } else {
+                leaf_test_words<R>(sv, q0, q1, q2, q3, w.o, w.d, w.acc);
+                hc.prim_tests += 1;
+                const int left = v >> BVH_SLOT_BITS;  // primitives of this leaf still to test
+                if (left > 0) w.node = ~((slot + 1) | ((left - 1) << BVH_SLOT_BITS));
+                else walk_pop(w, s_stack, spill);
+            }
+        }
+    }
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        hc.prim_tests += __shfl_xor(hc.prim_tests, sh);
+        hc.node_tests += __shfl_xor(hc.node_tests, sh);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&s_ctr.v[COUNTER_PRIM_TESTS], hc.prim_tests);
+        atomicAdd(&s_ctr.v[COUNTER_NODE_TESTS], hc.node_tests);
+    }
+    __syncthreads();
+    counters_flush(s_ctr, wp.block_counters);
 }
 
 // ------------------------------------------------------------------ shade + regenerate + compact
@@ -254,9 +358,14 @@ hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_
 }
 
 hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity,
-                                 hipStream_t stream) {
+                                 int persistent_blocks, hipStream_t stream) {
     const dim3 grid(wp.capacity / (uint32_t)WF_HIT_BLOCK), block(WF_HIT_BLOCK);
-    if (bvh)
+    if (bvh && sv.n_bvh_prims >= 2) {
+        // persistent waves: as many blocks as the device holds at once, never more than there are rays
+        const uint32_t want = grid.x < (uint32_t)persistent_blocks ? grid.x : (uint32_t)persistent_blocks;
+        static const int refill_min = [] { const char* e = getenv("RRT_DEBUG_REFILL_MIN"); return e ? atoi(e) : WF_REFILL_MIN; }();  // experiments
+        hipLaunchKernelGGL(wf_closest_hit_tree, dim3(want), dim3(BVH_BLOCK), 0, stream, sv, wp, parity, refill_min);
+    } else if (bvh)
         hipLaunchKernelGGL(wf_closest_hit<true>, grid, block, 0, stream, sv, wp, parity);
     else
         hipLaunchKernelGGL(wf_closest_hit<false>, grid, block, 0, stream, sv, wp, parity);

@@ -18,7 +18,7 @@ for rep in range(2):
     print("render:", {k: st[k] for k in ("samples", "rays", "prim_tests", "node_tests", "kernel_ms")},
           "Msamples/s %.1f Mrays/s %.1f node/ray %.1f prim/ray %.2f" % (st["samples"] / st["kernel_ms"] / 1e3, st["rays"] / st["kernel_ms"] / 1e3,
           st["node_tests"] / st["rays"], st["prim_tests"] / st["rays"]), flush=True)
-img, _ = be.postprocess(rgb, rc.spp, rc.post_desc())
+img = be.postprocess(rgb, rc.spp, rc.post_desc())
 from PIL import Image
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 Image.fromarray(img).save(os.path.join(ROOT, "gpurun_out", "c5.png"))
