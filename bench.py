@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """Headline benchmark: Cornell Box 500x500, stratified 16384 spp per GPU (MCPT, depth 2/6).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--pipeline auto|fused|wavefront]
 
-One step = one full pass of the hot path: every rank renders its 16384 sample
-indices of every pixel into an HBM-resident accumulator (rrt_render_accumulate),
-the accumulators are summed on rank 0 (RCCL reduce, N > 1) and rank 0 runs the
+One step = one full pass of the hot path: every rank renders its sample indices
+of every pixel into an HBM-resident accumulator (rrt_render_accumulate), the
+accumulators are summed on rank 0 (RCCL reduce, N > 1) and rank 0 runs the
 fused post-process.  Weak scaling: per-GPU work is fixed, the image gets
-N x 16384 samples per pixel.  Rank 0 prints ONE JSON line.
+N x (samples per GPU) samples per pixel.  Rank 0 prints ONE JSON line.
+
+Workloads (the default is the one the headline metric is quoted on):
+    cornell       configs/cornell_box, 500x500, 128x128 strata per GPU
+    smallpt       configs/smallpt, 1024x768, 128x128 strata per GPU
+    cornell_cube  configs/cornell_cube (Cornell box + assets/test.ply), 1024x1024, 64x64 strata per GPU
+    mesh_1m       configs/mesh_1m (Cornell shell + two generated 500k-triangle meshes), 3840x2160,
+                  32x32 strata per GPU; closest hit through the GPU-built LBVH
 """
 import argparse
 import json
@@ -27,25 +34,45 @@ FLOPS_PER_BOUNCE = [0, 110, 140, 30, 90]  # emissive, lambertian, phong, reflect
 FLOPS_RAYGEN = 25
 
 
-def scene_flops_per_ray(flat):
+FLOPS_PER_NODE_TEST = 24  # one ray/box slab test
+QUEUE_BYTES_PER_RAY = 88  # wavefront pipeline: ray 24 B + throughput 12 B + ids 8 B, written and read once per bounce
+
+# name -> (scene file, width, height, strata per axis per GPU, CPU-baseline strata per axis or None)
+WORKLOADS = {
+    "cornell": ("configs/cornell_box/scene.toml", 500, 500, 128, 32),
+    "smallpt": ("configs/smallpt/scene.toml", 1024, 768, 128, 16),
+    "cornell_cube": ("configs/cornell_cube/scene.toml", 1024, 1024, 64, 16),
+    "mesh_1m": ("configs/mesh_1m/scene.toml", 3840, 2160, 32, None),  # the reference scans 1 M triangles per ray
+}
+
+
+def scene_flops(flat):
+    """(flops of a linear scan of the whole scene, mean flops of one primitive test)."""
     import numpy as np
 
     names = ["sphere", "plane", "triangle", "quad"]
     counts = np.bincount(flat.prims["type"], minlength=4)
-    return int(sum(FLOPS_PER_PRIM_TEST[names[k]] * int(counts[k]) for k in range(4)))
+    scan = int(sum(FLOPS_PER_PRIM_TEST[names[k]] * int(counts[k]) for k in range(4)))
+    return scan, scan / max(int(counts.sum()), 1)
 
 
-def algorithmic_flops(stats, flops_per_ray):
-    return (stats["rays"] * flops_per_ray + sum(b * f for b, f in zip(stats["bounces"], FLOPS_PER_BOUNCE))
-            + stats["samples"] * FLOPS_RAYGEN)
+def algorithmic_flops(stats, flat):
+    """Closest-hit arithmetic actually asked for (every primitive per ray in a linear scan; node and
+    primitive tests from the device counters through the tree) + shading + ray generation."""
+    scan, per_prim = scene_flops(flat)
+    if stats["node_tests"]:
+        hit = stats["node_tests"] * FLOPS_PER_NODE_TEST + stats["prim_tests"] * per_prim
+    else:
+        hit = stats["rays"] * scan
+    return hit + sum(b * f for b, f in zip(stats["bounces"], FLOPS_PER_BOUNCE)) + stats["samples"] * FLOPS_RAYGEN
 
 
-def cpu_baseline(flat, threads):
+def cpu_baseline(flat, name, width, height, side, threads):
     """The f64 CPU restatement of the reference renderer (oracle/), timed on a bounded sample."""
     from oracle import oracle_py as O
     from rustraytracer_amd import config
 
-    rc = config.stratified_config(500, 500, 32, 32)  # same scene / image / tracer, 1024 spp
+    rc = config.stratified_config(width, height, side, side)  # same scene / image / tracer, fewer spp
     t0 = time.perf_counter()
     _, st = O.render_accumulate(flat, rc.render_desc(), n_threads=threads)
     dt = time.perf_counter() - t0
@@ -55,8 +82,9 @@ def cpu_baseline(flat, threads):
         "mrays_per_s": st["rays"] / dt / 1e6,
         "cores": threads,
         "kind": "port",
-        "sample": "Cornell Box 500x500 stratified 32x32 = 1024 spp (256 M samples), f64 C restatement of the "
-                  "reference renderer, 16x16 tiles over %d threads, %.1f s" % (threads, dt),
+        "sample": "%s %dx%d stratified %dx%d = %d spp (%.0f M samples), f64 C restatement of the reference "
+                  "renderer, 16x16 tiles over %d threads, %.1f s"
+                  % (name, width, height, side, side, side * side, st["samples"] / 1e6, threads, dt),
     }
 
 
@@ -65,7 +93,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-side", type=int, default=128, help="strata per axis per GPU (128 -> 16384 spp)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell")
+    ap.add_argument("--pipeline", choices=["auto", "fused", "wavefront"], default="auto")
+    ap.add_argument("--spp-side", type=int, default=0, help="strata per axis per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -91,17 +121,30 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    flat = config.load_scene(os.path.join(ROOT, "configs", "cornell_box", "scene.toml"))
+    scene_file, width, height, default_side, cpu_side = WORKLOADS[args.workload]
+    if args.workload == "mesh_1m":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_c5_assets
+
+        if local_rank == 0:
+            make_c5_assets.main()  # deterministic generator; the 25 MB of PLY are not committed
+        if world > 1:
+            dist.barrier()
+    flat = config.load_scene(os.path.join(ROOT, scene_file))
     be = api.Backend(local_rank)
     scene = api.Scene(flat)
     stream = torch.cuda.current_stream()
     be.set_stream(stream.cuda_stream)
 
-    side = args.spp_side
+    side = args.spp_side or default_side
     xs, ys = D.weak_scaling_strata(side, side, world)
-    rc = config.stratified_config(500, 500, xs, ys)
+    rc = config.stratified_config(width, height, xs, ys)
     lo, hi = D.shard_range(rc.spp, rank, world)
-    desc = rc.render_desc(sample_begin=lo, sample_end=hi)
+    pipeline = {"auto": api.PIPELINE_AUTO, "fused": api.PIPELINE_FUSED, "wavefront": api.PIPELINE_WAVEFRONT}[args.pipeline]
+    desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline)
+    # what AUTO resolves to (include/rrt.h): the tree for more than 48 primitives, and with it the wavefront pipeline
+    use_tree = flat.n_prims > 48
+    wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and use_tree)
     post = rc.post_desc()
     acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32, device="cuda")
     img = torch.zeros((rc.height, rc.width, 3), dtype=torch.uint8, device="cuda")
@@ -123,13 +166,12 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
-    tot = {"samples": 0, "rays": 0, "bounces": [0] * 5, "kernel_ms": 0.0, "nonfinite": 0}
+    tot = {"samples": 0, "rays": 0, "bounces": [0] * 5, "kernel_ms": 0.0, "nonfinite": 0, "node_tests": 0,
+           "prim_tests": 0}
     for _ in range(args.steps):
         st = step()
-        tot["samples"] += st["samples"]
-        tot["rays"] += st["rays"]
-        tot["kernel_ms"] += st["kernel_ms"]
-        tot["nonfinite"] += st["nonfinite"]
+        for k in ("samples", "rays", "kernel_ms", "nonfinite", "node_tests", "prim_tests"):
+            tot[k] += st[k]
         tot["bounces"] = [a + b for a, b in zip(tot["bounces"], st["bounces"])]
     fence()
     elapsed = time.perf_counter() - t0
@@ -143,20 +185,22 @@ def main():
     all_samples, all_rays = float(counts[0].item()), float(counts[1].item())
 
     if rank == 0:
-        fpr = scene_flops_per_ray(flat)
-        flops = algorithmic_flops(tot, fpr)  # rank 0's launches
+        fpr = scene_flops(flat)[0]
+        flops = algorithmic_flops(tot, flat)  # rank 0's launches
         kernel_s = tot["kernel_ms"] / 1e3
         achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "cornell" and not wavefront:
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get("bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "Msamples/s (whole node), Cornell Box 500x500 MCPT",
+            "metric": "Msamples/s (whole node), %s MCPT" % {"cornell": "Cornell Box 500x500", "smallpt": "smallpt 1024x768",
+                                                             "cornell_cube": "Cornell Box + test.ply 1024x1024",
+                                                             "mesh_1m": "1M-triangle mesh scene 3840x2160"}[args.workload],
             "value": all_samples / elapsed / 1e6,
             "unit": "Msamples/s",
             "mrays_per_s": all_rays / elapsed / 1e6,
@@ -168,13 +212,15 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic (Cornell Box scene of the reference configs; PLY meshes reconstructed from the "
-                    "canonical measurements because the reference ships LFS stubs)",
+            "data": "synthetic (scenes of the reference configs; Cornell PLY meshes reconstructed from the canonical "
+                    "measurements because the reference ships LFS stubs; the 1M-triangle meshes are generated)",
             "config": {
-                "workload": "configs/cornell_box scene, 500x500, stratified %dx%d = %d spp in total, %d sample "
-                            "indices per GPU, MCPT min_depth 2 / max_depth 6" % (xs, ys, rc.spp, hi - lo),
-                "pipeline": "fused (register-resident paths, lane regeneration)",
-                "reduce": "RCCL sum-reduce of %.1f MB fp32 accumulators to rank 0" % (D.message_bytes(500, 500) / 1e6)
+                "workload": "%s, %dx%d, stratified %dx%d = %d spp in total, %d sample indices per GPU, MCPT "
+                            "min_depth 2 / max_depth 6" % (scene_file, width, height, xs, ys, rc.spp, hi - lo),
+                "pipeline": "wavefront (SoA ray/hit queues in HBM, ballot/rank compaction)" if wavefront
+                else "fused (register-resident paths, lane regeneration)",
+                "closest_hit": "GPU-built LBVH (4-wide quantised nodes)" if use_tree else "linear scan (wave-uniform)",
+                "reduce": "RCCL sum-reduce of %.1f MB fp32 accumulators to rank 0" % (D.message_bytes(width, height) / 1e6)
                 if world > 1 else "none",
                 "samples_per_step": int(all_samples / args.steps),
                 "rays_per_sample": all_rays / all_samples,
@@ -182,7 +228,8 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp32",
-                "kernel": "render_fused<float>",
+                "kernel": ("wf_closest_hit_tree + wf_shade" if use_tree else "wf_closest_hit + wf_shade") if wavefront
+                else "render_fused<float>",
                 "achieved": achieved,
                 "peak": PEAK_FP32_VALU_TFLOPS,
                 "unit": "TFLOP/s",
@@ -193,9 +240,17 @@ def main():
                 "avg_launch_ms": tot["kernel_ms"] / args.steps,
             },
         }
+        if use_tree:
+            out["config"]["node_tests_per_ray"] = tot["node_tests"] / max(tot["rays"], 1)
+            out["config"]["prim_tests_per_ray"] = tot["prim_tests"] / max(tot["rays"], 1)
+        if wavefront:
+            out["roofline"]["queue_traffic_algorithmic_GBps"] = tot["rays"] * QUEUE_BYTES_PER_RAY / kernel_s / 1e9
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 16)
-            out["cpu_baseline"] = cpu_baseline(flat, threads)
+            if cpu_side is None:
+                out["cpu_baseline"] = None  # a linear scan of 1 M triangles per ray: not timed
+            else:
+                threads = min(os.cpu_count() or 1, 16)
+                out["cpu_baseline"] = cpu_baseline(flat, args.workload, width, height, cpu_side, threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

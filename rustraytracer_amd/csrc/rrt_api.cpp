@@ -294,8 +294,9 @@ struct DevBuf {
 
 // Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO.
 const size_t kAutoBvhThreshold = 48;
-// Subtrees of at most this many primitives are folded into one leaf.
-const int kBvhLeafMax = 4;
+// Subtrees of at most this many primitives are folded into one leaf.  A traversal step costs one
+// 64-byte fetch whether it reads a node or a primitive; 2 minimises their sum on triangle meshes.
+const int kBvhLeafMax = 2;
 
 float round_down(double x) {
     float f = (float)x;
@@ -537,9 +538,11 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
 }
 
 // ------------------------------------------------------------------ wavefront pipeline
-// Paths per queue.  4 Mi paths = 448 MiB for the two queues; one trip then moves ~0.5 GB through
-// HBM and costs two kernel launches, so larger queues buy nothing.
-const uint32_t kWfDefaultCapacity = 1u << 22;
+// Paths per queue (56 bytes per path and queue).  A trip of the linear-scan pipeline costs two
+// kernel launches and streams the queue through HBM once; the tree kernel is persistent and ends
+// every trip with a tail of half-empty waves, so it wants several rays per lane and trip.
+const uint32_t kWfCapacityLinear = 1u << 22;
+const uint32_t kWfCapacityTree = 1u << 24;
 
 int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity) {
     if (be->wf_mem && be->wf_capacity == capacity) return RRT_OK;
@@ -585,7 +588,7 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
                     rp.max_depth, rrt::WF_MAX_DEPTH);
     const uint64_t n_pixels = (uint64_t)rp.width * rp.height;
     const uint64_t total = n_pixels * rp.n_samples;
-    uint32_t capacity = kWfDefaultCapacity;
+    uint32_t capacity = use_bvh ? kWfCapacityTree : kWfCapacityLinear;
     if (const char* e = getenv("RRT_DEBUG_WF_CAPACITY")) {  // experiments and tests
         long v = atol(e);
         if (v >= 64 && v <= (1l << 26)) capacity = (uint32_t)v;

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
 // one-ray-per-lane leaves most lanes idle most of the time.  Here a wave is persistent: it walks its
 // own blocks of 64 rays (block b belongs to wave b % n_waves, no shared counter) and hands the next
 // rays to lanes as they finish, whenever at least WF_REFILL_MIN lanes are idle.
-constexpr int WF_REFILL_MIN = 12;
+constexpr int WF_REFILL_MIN = 8;
 
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
 wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min) {
