@@ -164,7 +164,10 @@ def _ply_rows_ascii(rows, props):
         i = 0
         for p in props:
             if p[0] == "scalar":
-                out[p[1]].append(float(r[i]))
+                v = float(r[i])
+                if _PLY_SCALAR[p[2]][1] == "Float":
+                    v = float(np.float32(v))  # the file value is an f32 (ply-rs parses the token as f32)
+                out[p[1]].append(v)
                 i += 1
             else:
                 n = int(r[i])
