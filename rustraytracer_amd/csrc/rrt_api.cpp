@@ -313,13 +313,7 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
     std::vector<int32_t> bounded, unbounded;  // scan-order indices
     std::vector<float> lo, hi;
     double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (size_t g = 0; g < sc->prims.size(); ++g) {
-        const rrt_prim& p = sc->prims[g];
-        if (p.type == RRT_PRIM_PLANE) {
-            unbounded.push_back((int32_t)g);
-            continue;
-        }
-        double blo[3], bhi[3];
+    auto bounds = [](const rrt_prim& p, double blo[3], double bhi[3]) {
         if (p.type == RRT_PRIM_SPHERE) {
             for (int k = 0; k < 3; ++k) { blo[k] = p.v[k] - std::fabs(p.v[3]); bhi[k] = p.v[k] + std::fabs(p.v[3]); }
         } else {
@@ -332,11 +326,29 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
                 }
             }
         }
-        // pad: the f32 ray test may accept a point a few 1e-7 (relative) outside the exact primitive
+    };
+    // Largest coordinate magnitude a traversal works with: the scene's bounded primitives and the
+    // camera (every other ray starts on a surface).  The slab tests are exact up to a few f32 ulps
+    // of the distance between ray origin and box, and the f32 primitive tests accept points a few
+    // 1e-7 (relative to that scale) outside the exact primitive; the boxes are padded for both.
+    double scale = 0;
+    for (int k = 0; k < 3; ++k) scale = std::fmax(scale, std::fabs(sc->camera.origin[k]));
+    for (const rrt_prim& p : sc->prims) {
+        if (p.type == RRT_PRIM_PLANE) continue;
+        double blo[3], bhi[3];
+        bounds(p, blo, bhi);
+        for (int k = 0; k < 3; ++k) scale = std::fmax(scale, std::fmax(std::fabs(blo[k]), std::fabs(bhi[k])));
+    }
+    for (size_t g = 0; g < sc->prims.size(); ++g) {
+        const rrt_prim& p = sc->prims[g];
+        if (p.type == RRT_PRIM_PLANE) {
+            unbounded.push_back((int32_t)g);
+            continue;
+        }
+        double blo[3], bhi[3];
+        bounds(p, blo, bhi);
         double ext = std::fmax(std::fmax(bhi[0] - blo[0], bhi[1] - blo[1]), bhi[2] - blo[2]);
-        double mag = 0;
-        for (int k = 0; k < 3; ++k) mag = std::fmax(mag, std::fmax(std::fabs(blo[k]), std::fabs(bhi[k])));
-        double pad = 1e-4 * ext + 4e-6 * mag + 1e-30;
+        double pad = 1e-4 * ext + 4e-6 * scale + 1e-30;
         for (int k = 0; k < 3; ++k) {
             lo.push_back(round_down(blo[k] - pad));
             hi.push_back(round_up(bhi[k] + pad));

@@ -75,8 +75,16 @@ template <typename R>
 RRT_DEV void walk_start(TreeWalk<R>& w, V3<R> o, V3<R> d) {
     w.o = o;
     w.d = d;
-    // 1/d with the sign of d kept for zero components: +-inf slabs work with min/max that drop NaN
-    w.inv_d = mk<R>(R(1) / d.x, R(1) / d.y, R(1) / d.z);
+    // 1/d for the slab tests, with |d| floored at a value far below any direction cosine that matters:
+    // a ray whose component is exactly zero is treated as tilted by 1e-18 (a shift of 1e-18 t, nothing
+    // beside the padding of the boxes), and every product in the slab arithmetic stays finite -- an
+    // inf or NaN there would switch the culling of that axis off, and one ray that visits a whole
+    // million-node tree takes longer than a million ordinary rays.
+    const R tiny = sizeof(R) == 4 ? R(1e-18) : R(1e-150);
+    const R dx = Num<R>::abs(d.x) < tiny ? (d.x < R(0) ? -tiny : tiny) : d.x;
+    const R dy = Num<R>::abs(d.y) < tiny ? (d.y < R(0) ? -tiny : tiny) : d.y;
+    const R dz = Num<R>::abs(d.z) < tiny ? (d.z < R(0) ? -tiny : tiny) : d.z;
+    w.inv_d = mk<R>(R(1) / dx, R(1) / dy, R(1) / dz);
     w.sp = 0;
     w.node = 0;
 }
@@ -118,24 +126,24 @@ template <typename R>
 RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, uint4 q0, uint4 q1, uint4 q2, uint4 q3) {
     const R widen = sizeof(R) == 4 ? R(1.0000004) : R(1.0000000001);
     const R inf = Num<R>::tmax();
-    const float ox = __uint_as_float(q0.x), oy = __uint_as_float(q0.y), oz = __uint_as_float(q0.z);
-    const float sx = __uint_as_float((q0.w & 0xffu) << 23), sy = __uint_as_float(((q0.w >> 8) & 0xffu) << 23),
-                sz = __uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+    // plane distance t = (org + q s - o) / d = q (s / d) + (org - o) / d: two multiplies and a subtract per
+    // axis and node, then one convert and one FMA per plane.  Rounding differs from decoding the plane
+    // first by a few ulps of the ray-origin-to-node distance; the builder's padding is sized for that.
+    const R sx = (R)__uint_as_float((q0.w & 0xffu) << 23), sy = (R)__uint_as_float(((q0.w >> 8) & 0xffu) << 23),
+            sz = (R)__uint_as_float(((q0.w >> 16) & 0xffu) << 23);
+    const R ax_ = sx * w.inv_d.x, ay_ = sy * w.inv_d.y, az_ = sz * w.inv_d.z;
+    const R bx_ = ((R)__uint_as_float(q0.x) - w.o.x) * w.inv_d.x;
+    const R by_ = ((R)__uint_as_float(q0.y) - w.o.y) * w.inv_d.y;
+    const R bz_ = ((R)__uint_as_float(q0.z) - w.o.z) * w.inv_d.z;
     const uint32_t qlx = q1.x, qly = q1.y, qlz = q1.z, qhx = q1.w, qhy = q2.x, qhz = q2.y;
     const int link[4] = {(int)q2.z, (int)q2.w, (int)q3.x, (int)q3.y};
     R dist[4];
     int child[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float lox = __builtin_fmaf(byte_to_float(qlx, k), sx, ox);
-        const float loy = __builtin_fmaf(byte_to_float(qly, k), sy, oy);
-        const float loz = __builtin_fmaf(byte_to_float(qlz, k), sz, oz);
-        const float hix = __builtin_fmaf(byte_to_float(qhx, k), sx, ox);
-        const float hiy = __builtin_fmaf(byte_to_float(qhy, k), sy, oy);
-        const float hiz = __builtin_fmaf(byte_to_float(qhz, k), sz, oz);
-        const R ax = ((R)lox - w.o.x) * w.inv_d.x, bx = ((R)hix - w.o.x) * w.inv_d.x;
-        const R ay = ((R)loy - w.o.y) * w.inv_d.y, by = ((R)hiy - w.o.y) * w.inv_d.y;
-        const R az = ((R)loz - w.o.z) * w.inv_d.z, bz = ((R)hiz - w.o.z) * w.inv_d.z;
+        const R ax = (R)byte_to_float(qlx, k) * ax_ + bx_, bx = (R)byte_to_float(qhx, k) * ax_ + bx_;
+        const R ay = (R)byte_to_float(qly, k) * ay_ + by_, by = (R)byte_to_float(qhy, k) * ay_ + by_;
+        const R az = (R)byte_to_float(qlz, k) * az_ + bz_, bz = (R)byte_to_float(qhz, k) * az_ + bz_;
         const R en = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
         const R ex = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz)) * widen;
         child[k] = link[k];
