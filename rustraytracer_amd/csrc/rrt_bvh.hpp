@@ -179,11 +179,11 @@ RRT_DEV void leaf_test_words(const SceneView<R>& sv, uint4 q0, uint4 q1, uint4 q
         const R f8 = __uint_as_float(q2.x), f9 = __uint_as_float(q2.y), f10 = __uint_as_float(q2.z), f11 = __uint_as_float(q2.w);
         const R best_t = Num<R>::tmax();
         R nd = f0 * d.x + f1 * d.y + f2 * d.z;
-        R no = ((f3 - f0 * o.x) - f1 * o.y) - f2 * o.z;
+        R no = f3 - ((f0 * o.x + f1 * o.y) + f2 * o.z);
         t = no * Num<R>::rcp(nd);
         V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-        R a = f4 * P.x + (f5 * P.y + (f6 * P.z + f7));
-        R b = f8 * P.x + (f9 * P.y + (f10 * P.z + f11));
+        R a = ((f4 * P.x + f5 * P.y) + f6 * P.z) + f7;
+        R b = ((f8 * P.x + f9 * P.y) + f10 * P.z) + f11;
         R det_ok = Num<R>::abs(nd) - Num<R>::eps();
         if (type == PRIM_PGRAM) {
             R h = min3(R(0.5) - Num<R>::abs(a), R(0.5) - Num<R>::abs(b), det_ok);

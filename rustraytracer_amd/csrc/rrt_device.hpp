@@ -282,15 +282,15 @@ template <typename R, int TYPE>
 RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
     const R RRT_CONSTANT* f = p->f;
     if (TYPE >= PRIM_TRIANGLE) {
-        // (the order of operations is the one of scan_run_pairs: a primitive gets the same t and
-        // the same verdict from the wave-uniform scan, the packed pair scan and a tree leaf)
+        // (the order of operations is the one of scan_run_pairs and leaf_test_words: a primitive gets
+        // the same t and the same verdict from the wave-uniform scan, the packed pair scan and a tree leaf)
         R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-        R no = ((f[3] - f[0] * o.x) - f[1] * o.y) - f[2] * o.z;
+        R no = f[3] - ((f[0] * o.x + f[1] * o.y) + f[2] * o.z);
         R t = no * Num<R>::rcp(nd);
         t_out = t;
         V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-        R a = f[4] * P.x + (f[5] * P.y + (f[6] * P.z + f[7]));
-        R b = f[8] * P.x + (f[9] * P.y + (f[10] * P.z + f[11]));
+        R a = ((f[4] * P.x + f[5] * P.y) + f[6] * P.z) + f[7];
+        R b = ((f[8] * P.x + f[9] * P.y) + f[10] * P.z) + f[11];
         R det_ok = Num<R>::abs(nd) - Num<R>::eps();
         if (TYPE == PRIM_PGRAM) {
             // parallelogram: alpha' = 1 - alpha and beta' = 1 - beta, so the two-triangle
@@ -299,8 +299,8 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
             return min3(h, t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
         }
         if (TYPE == PRIM_QUAD) {
-            R a2 = f[12] * P.x + (f[13] * P.y + (f[14] * P.z + f[15]));
-            R b2 = f[16] * P.x + (f[17] * P.y + (f[18] * P.z + f[19]));
+            R a2 = ((f[12] * P.x + f[13] * P.y) + f[14] * P.z) + f[15];
+            R b2 = ((f[16] * P.x + f[17] * P.y) + f[18] * P.z) + f[19];
             R nd2 = f[20] * d.x + f[21] * d.y + f[22] * d.z;
             R second = min3(a2, b2, Num<R>::abs(nd2) - Num<R>::eps());  // the (v2, v3, v1) corner
             R inside = fmax(R(1) - (a + b), second);                      // alpha + beta <= 1, or that corner
@@ -334,7 +334,7 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
     }
     // plane, src/shapes/plane.rs:25-44
     R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-    R no = ((f[3] - f[0] * o.x) - f[1] * o.y) - f[2] * o.z;
+    R no = f[3] - ((f[0] * o.x + f[1] * o.y) + f[2] * o.z);
     R t = no * Num<R>::rcp(nd);
     t_out = t;
     return min3(Num<R>::abs(nd) - Num<R>::eps(), t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
@@ -380,21 +380,28 @@ RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int
     const int n_pairs = (count + 1) >> 1;
     for (int k = 0; k < n_pairs; ++k) {
         const R2 RRT_CONSTANT* f = reinterpret_cast<const R2 RRT_CONSTANT*>(pairs[k].g);
+        // (every packed operation below reads at most one scalar register pair: the constant terms
+        //  f[3], f[7], f[11] enter through an add of their own, not as the addend of an FMA whose
+        //  multiplicand is a scalar pair too, which would cost a move into vector registers each)
         R2 nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-        R2 no = ((f[3] - f[0] * o.x) - f[1] * o.y) - f[2] * o.z;
+        R2 no = f[3] - ((f[0] * o.x + f[1] * o.y) + f[2] * o.z);
         R2 rc;
         rc.x = Num<R>::rcp(nd.x);
         rc.y = Num<R>::rcp(nd.y);
         R2 t = no * rc;
         R2 px = o.x + t * d.x, py = o.y + t * d.y, pz = o.z + t * d.z;
-        R2 a = f[4] * px + (f[5] * py + (f[6] * pz + f[7]));
-        R2 b = f[8] * px + (f[9] * py + (f[10] * pz + f[11]));
+        R2 a = ((f[4] * px + f[5] * py) + f[6] * pz) + f[7];
+        R2 b = ((f[8] * px + f[9] * py) + f[10] * pz) + f[11];
         R2 tm = t - Num<R>::tmin();
-        R h0 = min3(R(0.5) - Num<R>::abs(a.x), R(0.5) - Num<R>::abs(b.x), Num<R>::abs(nd.x) - Num<R>::eps());
+        // |a| <= 1/2 <=> 1/4 - a^2 >= 0 exactly (the square of the f32/f64 next to 1/2 rounds to the
+        // proper side of 1/4), and the square form is one packed FMA for both records
+        R2 qa = R(0.25) - a * a;
+        R2 qb = R(0.25) - b * b;
+        R h0 = min3((R)qa.x, (R)qb.x, Num<R>::abs(nd.x) - Num<R>::eps());
         const bool ok0 = min3(h0, tm.x, headroom(best_t, (R)t.x)) >= R(0);
         best_t = ok0 ? t.x : best_t;
         best_g = ok0 ? first + 2 * k : best_g;
-        R h1 = min3(R(0.5) - Num<R>::abs(a.y), R(0.5) - Num<R>::abs(b.y), Num<R>::abs(nd.y) - Num<R>::eps());
+        R h1 = min3((R)qa.y, (R)qb.y, Num<R>::abs(nd.y) - Num<R>::eps());
         const bool ok1 = min3(h1, tm.y, headroom(best_t, (R)t.y)) >= R(0);
         best_t = ok1 ? t.y : best_t;
         best_g = ok1 ? first + 2 * k + 1 : best_g;
