@@ -113,13 +113,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+    # RRT_BENCH_REHEARSAL=1: every rank on GPU 0, gloo instead of RCCL -- exercises the multi-rank code path
+    # (shards, reduce, max-over-ranks timing) on a one-GPU box; the line it prints is marked and is no result
+    rehearsal = os.environ.get("RRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     scene_file, width, height, default_side, cpu_side = WORKLOADS[args.workload]
     if args.workload == "mesh_1m":
@@ -152,7 +160,12 @@ def main():
     def step():
         acc.zero_()
         _, st = be.render_accumulate(scene, desc, acc)
-        D.reduce_sum(acc, dst=0)
+        if rehearsal and world > 1:
+            host = acc.cpu()
+            D.reduce_sum(host, dst=0)
+            acc.copy_(host)
+        else:
+            D.reduce_sum(acc, dst=0)
         if rank == 0:
             be.postprocess(acc, rc.spp, post, out=img)
         return st
@@ -176,8 +189,9 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    counts = torch.tensor([tot["samples"], tot["rays"]], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    cdev = "cpu" if rehearsal else "cuda"
+    counts = torch.tensor([tot["samples"], tot["rays"]], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -240,6 +254,8 @@ def main():
                 "avg_launch_ms": tot["kernel_ms"] / args.steps,
             },
         }
+        if rehearsal:
+            out["rehearsal"] = "all ranks on GPU 0, gloo: not a measurement"
         if use_tree:
             out["config"]["node_tests_per_ray"] = tot["node_tests"] / max(tot["rays"], 1)
             out["config"]["prim_tests_per_ray"] = tot["prim_tests"] / max(tot["rays"], 1)

@@ -1,0 +1,45 @@
+"""bench.py end to end on a GPU: the JSON contract of the single-GPU line, and a two-rank rehearsal of
+the multi-GPU path (both ranks on GPU 0, gloo in place of RCCL; see RRT_BENCH_REHEARSAL in bench.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def last_json(text):
+    return json.loads([l for l in text.splitlines() if l.startswith("{")][-1])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--spp-side", "8"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "Msamples/s"
+    assert d["config"]["samples_per_step"] == 500 * 500 * 64 and d["vs_baseline"] is None and d["dtype"] == "f32"
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and d["value"] > 20 * cb["value"]
+
+
+def test_two_rank_rehearsal():
+    env = dict(os.environ, RRT_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--spp-side", "8", "--workload", "smallpt"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "rehearsal" in d
+    assert d["config"]["samples_per_step"] == 2 * 1024 * 768 * 64  # both ranks' 64 sample indices of every pixel
+    assert "cpu_baseline" not in d  # timed on rank 0 at N = 1 only
