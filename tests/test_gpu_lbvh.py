@@ -41,7 +41,7 @@ def mesh_scene(n_tri, seed=2, with_quads=False):
 
 
 def cornell_with_cube(cfg, cornell):
-    """BASELINE config 4: the Cornell box plus assets/test.ply (a unit cube of 6 quads) as a 7th object,
+    """The cornell_cube benchmark scene: the Cornell box plus assets/test.ply (a unit cube of 6 quads) as a 7th object,
     scaled to 0.12 m and set on the floor in front of the boxes, Phong material."""
     import copy
     verts, _, faces = cfg.load_mesh(os.path.join(ROOT, "assets", "test.ply"))
@@ -151,3 +151,71 @@ def test_degenerate_trees(gpu):
         for prec in (api.PRECISION_F32, api.PRECISION_F64):
             got = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LBVH)
             assert list(got[0]) == expect, (prims, got)
+
+
+def _rays(n, seed):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(-0.5, 0.5, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[: n // 8, 0] = 0.0  # a share of rays with an exactly-zero direction component (infinite slabs)
+    d[: n // 16, 1] = 0.0
+    d[: n // 8] /= np.linalg.norm(d[: n // 8], axis=1, keepdims=True)
+    return o, d
+
+
+@pytest.mark.parametrize("case", ["one", "two", "three", "planes_only", "identical", "degenerate", "far_offset"])
+def test_lbvh_edge_cases(gpu, case):
+    """Tiny trees, no tree at all, coincident and zero-area primitives, a scene far from the origin:
+    tree and scan must agree bit for bit, axis-parallel rays included."""
+    api, be = gpu
+    tri = lambda z, dx=0.0: [[-1 + dx, -1, z], [2 + dx, -1, z], [-1 + dx, 2, z]]
+    quad = lambda z: [[-1, -1, z], [1, -1, z], [1, 1, z], [-1, 1, z]]
+    mats = [(_abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)]
+    shift = np.zeros(3)
+    if case == "one":
+        prims = [(2, 0, 0, tri(-2))]
+    elif case == "two":
+        prims = [(2, 0, 0, tri(-2)), (0, 0, 1, [0, 0, 3, 1.0])]
+    elif case == "three":
+        prims = [(2, 0, 0, tri(-2)), (3, 0, 1, quad(-3)), (0, 0, 2, [0.5, 0.5, 2.5, 0.75])]
+    elif case == "planes_only":
+        prims = [(1, 0, 0, [0, 0, -2, 0, 0, 1]), (1, 0, 1, [0, -2, 0, 0, 1, 0]), (1, 0, 2, [3, 0, 0, 1, 0, 0])]
+    elif case == "identical":  # equal Morton codes: the position in the sorted order breaks the tie
+        prims = [(3 if i % 3 else 2, 0, i, quad(-2) if i % 3 else tri(-2)) for i in range(40)]
+    elif case == "degenerate":  # zero-area faces never hit anything (|n.d| < 1e-6) but must not break the build
+        prims = [(2, 0, 0, [[0, 0, -2]] * 3), (2, 0, 1, [[0, 0, -2], [1, 0, -2], [2, 0, -2]]), (2, 0, 2, tri(-3)),
+                 (3, 0, 3, quad(-4)), (2, 0, 4, [[5, 5, 5]] * 3)]
+    else:  # far_offset: coordinates ~1e4 with unit-size geometry
+        shift = np.array([1.0e4, -2.0e4, 3.0e4])
+        prims = [(2, 0, i, (np.array(tri(-2 - 0.1 * i, 0.05 * i)) + shift)) for i in range(30)]
+        prims.append((0, 0, 30, [*(np.array([0.0, 0.0, 2.0]) + shift), 0.5]))
+    sc = api.Scene(S.make_scene(prims, mats))
+    o, d = _rays(20000, seed=11)
+    o = o + shift
+    for prec in (api.PRECISION_F64, api.PRECISION_F32):
+        lin = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LINEAR)
+        bvh = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LBVH)
+        assert _same(lin, bvh), f"{case} prec {prec}"
+        if case != "degenerate":
+            assert (lin[0] >= 0).sum() > 1000
+    # and a render through both pipelines on the tree
+    from rustraytracer_amd import config as cfg
+    rc = cfg.stratified_config(32, 32, 2, 2)
+    a = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LBVH, pipeline=api.PIPELINE_FUSED))
+    b = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LBVH, pipeline=api.PIPELINE_WAVEFRONT))
+    c = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LINEAR, pipeline=api.PIPELINE_FUSED))
+    assert a[1]["rays"] == b[1]["rays"] == c[1]["rays"] and a[1]["bounces"] == b[1]["bounces"] == c[1]["bounces"]
+
+
+def test_empty_scene(gpu, cfg):
+    api, be = gpu
+    sc = api.Scene(S.make_scene([], []))
+    o, d = _rays(100, seed=1)
+    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH):
+        got = be.intersect(sc, o, d, accel=accel)
+        assert np.all(got[0] == -1) and np.all(np.isinf(got[2]))
+    rc = cfg.stratified_config(16, 16, 2, 2)
+    for pipe in (api.PIPELINE_FUSED, api.PIPELINE_WAVEFRONT):
+        rgb, st = be.render_accumulate(sc, rc.render_desc(pipeline=pipe))
+        assert st["samples"] == 16 * 16 * 4 and st["rays"] == st["samples"] and not rgb.any()
