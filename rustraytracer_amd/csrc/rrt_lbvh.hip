@@ -8,6 +8,7 @@
 //
 //   6. collapse_kernel subtrees of a few primitives become single leaves (slot ranges)
 //   7. widen_kernel    every binary node with its children expanded: the 4-wide nodes rays traverse
+//   8. reachable/compact the wide nodes rays can reach, packed to the front of the node array
 //
 // A binary node holds the boxes of BOTH children; child < 0 encodes a leaf, see BvhNode;
 // prim_of_slot[slot] = index into the bounds arrays.
@@ -167,6 +168,31 @@ __global__ void __launch_bounds__(256) widen_kernel(const BvhNode* __restrict__ 
     wide[i] = W;
 }
 
+// Wide node i is reached by rays iff binary node i sits at an even depth (odd levels are absorbed
+// into their parents) and is not inside a folded subtree.
+__global__ void __launch_bounds__(256)
+reachable_kernel(const int* __restrict__ node_parent, const int* __restrict__ range_count, int n, int leaf_max,
+                 int* __restrict__ flag) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    int depth = 0;
+    for (int p = node_parent[i]; p >= 0; p = node_parent[p]) ++depth;
+    flag[i] = ((depth & 1) == 0 && (i == 0 || range_count[i] > leaf_max)) ? 1 : 0;
+}
+
+// Packs the reachable wide nodes to the front of `out`, in index order (which is the sorted order of
+// the primitives, so a subtree stays contiguous), and renames the child links.
+__global__ void __launch_bounds__(256)
+compact_kernel(const WideNode* __restrict__ wide, const int* __restrict__ flag, const int* __restrict__ new_index, int n,
+               WideNode* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || !flag[i]) return;
+    WideNode W = wide[i];
+    for (int c = 0; c < 4; ++c)
+        if (W.child[c] >= 0) W.child[c] = new_index[W.child[c]];
+    out[new_index[i]] = W;
+}
+
 template <typename R>
 __global__ void __launch_bounds__(256)
 pack_leaves_kernel(const PrimRec<R>* __restrict__ prims, const int* __restrict__ prim_of_slot, int n,
@@ -222,6 +248,7 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
     if (n < 2 || n > BVH_MAX_PRIMS || leaf_max < 1 || leaf_max > 8) return hipErrorInvalidValue;
     hipError_t e;
     BvhNode* d_nodes = nullptr;
+    WideNode* wide_tmp = nullptr;
     unsigned long long *keys_in = nullptr, *keys_out = nullptr;
     unsigned int* index_in = nullptr;
     int *node_parent = nullptr, *leaf_parent = nullptr, *range_first = nullptr, *range_count = nullptr;
@@ -230,6 +257,7 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
     size_t temp_bytes = 0;
     auto cleanup = [&]() {
         (void)hipFree(d_nodes);
+        (void)hipFree(wide_tmp);
         (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(index_in); (void)hipFree(node_parent);
         (void)hipFree(leaf_parent); (void)hipFree(range_first); (void)hipFree(range_count); (void)hipFree(flags);
         (void)hipFree(temp);
@@ -267,7 +295,27 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
         hipLaunchKernelGGL(collapse_kernel, grid, block, 0, stream, d_nodes, n, range_first, range_count, leaf_max);
         LBVH_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(widen_kernel, grid, block, 0, stream, d_nodes, n, d_wide);
+    LBVH_TRY(hipMalloc(&wide_tmp, sizeof(WideNode) * (size_t)(n - 1)));
+    hipLaunchKernelGGL(widen_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp);
+    LBVH_TRY(hipGetLastError());
+    // only about half of the wide nodes are ever visited: pack those (twice the useful nodes per cache line)
+    int* flag = reinterpret_cast<int*>(flags);   // the refit flags are free again
+    int* new_index = leaf_parent;                // and so is this array
+    hipLaunchKernelGGL(reachable_kernel, grid, block, 0, stream, node_parent, range_count, n, leaf_max, flag);
+    LBVH_TRY(hipGetLastError());
+    {
+        size_t scan_bytes = 0;
+        LBVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, new_index, 0, (size_t)(n - 1), rocprim::plus<int>(), stream));
+        if (scan_bytes > temp_bytes) {
+            LBVH_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(temp);
+            temp = nullptr;
+            LBVH_TRY(hipMalloc(&temp, scan_bytes));
+            temp_bytes = scan_bytes;
+        }
+        LBVH_TRY(rocprim::exclusive_scan(temp, scan_bytes, flag, new_index, 0, (size_t)(n - 1), rocprim::plus<int>(), stream));
+    }
+    hipLaunchKernelGGL(compact_kernel, grid, block, 0, stream, wide_tmp, flag, new_index, n, d_wide);
     LBVH_TRY(hipGetLastError());
     LBVH_TRY(hipStreamSynchronize(stream));
 #undef LBVH_TRY
