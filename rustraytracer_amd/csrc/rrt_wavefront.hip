@@ -171,6 +171,14 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
             const uint4* rec = at_node ? reinterpret_cast<const uint4*>(sv.nodes + w.node)
                                        : reinterpret_cast<const uint4*>(sv.leaves + slot);
             const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+#ifdef RRT_EXP_EXTRA_VALU
+            {  // sensitivity experiment: extra dependent FMAs per step
+                float x = __uint_as_float(q0.x);
+#pragma unroll
+                for (int k = 0; k < RRT_EXP_EXTRA_VALU; ++k) x = __builtin_fmaf(x, 1.0000001f, 1e-9f);
+                if (x == 12345.678f) hc.node_tests += 1;
+            }
+#endif
             if (at_node) {
                 walk_node(w, s_stack, spill, q0, q1, q2, q3);
                 hc.node_tests += 1;

@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 
 #include "png_writer.hpp"
 #include "scene_host.hpp"
@@ -21,6 +23,8 @@ const char* kUsage =
     "  -r, --render-config <RENDER_CONFIG>  tracer / image / sampler / post-processing settings (TOML)\n"
     "  -o, --output <OUTPUT>                image file to write (.png or .ppm)\n"
     "      --device <N>                     GPU to render on [default: 0]\n"
+    "      --devices <A,B,...>              render on several GPUs: the sample indices of every pixel are split\n"
+    "                                       evenly, the radiance sums are added on the host\n"
     "      --seed <N>                       sampler seed (overrides `seed` of the render config)\n"
     "      --precision <f32|f64>            arithmetic of the kernels [default: f32]\n"
     "      --accel <auto|linear|lbvh>       closest-hit structure [default: auto]\n"
@@ -33,6 +37,7 @@ const char* kUsage =
 struct Args {
     std::string scene, render, output, stats_json, dump_scene;
     int device = 0;
+    std::vector<int> devices;
     bool has_seed = false;
     unsigned long long seed = 0;
     uint32_t precision = RRT_PRECISION_F32, accel = RRT_ACCEL_AUTO, pipeline = RRT_PIPELINE_AUTO;
@@ -79,6 +84,18 @@ Args parse_args(int argc, char** argv) {
             a.output = value();
         } else if (arg == "--device") {
             a.device = std::atoi(value().c_str());
+        } else if (arg == "--devices") {
+            std::string list = value();
+            size_t pos = 0;
+            while (pos <= list.size()) {
+                size_t comma = list.find(',', pos);
+                std::string item = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+                if (item.empty() || item.find_first_not_of("0123456789") != std::string::npos)
+                    usage_error("invalid value '" + list + "' for '--devices'");
+                a.devices.push_back(std::atoi(item.c_str()));
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
         } else if (arg == "--seed") {
             a.seed = std::strtoull(value().c_str(), nullptr, 10);
             a.has_seed = true;
@@ -154,24 +171,68 @@ int run(const Args& a) {
     if (a.has_seed) rs.render.seed = a.seed;
     const double t_load = seconds_since(t_start);
 
-    rrt_scene_desc desc = sc.desc();
-    rrt_scene* scene = nullptr;
-    rrt_backend* backend = nullptr;
-    RRT_CALL(rrt_scene_create(&desc, &scene));
-    if (rrt_backend_create("hip", a.device, &backend) != RRT_OK) {
-        std::string msg = rrt_last_error();
-        rrt_scene_destroy(scene);
-        throw std::runtime_error("rrt_backend_create: " + msg);
-    }
-    std::vector<uint8_t> image((size_t)rs.render.width * rs.render.height * 3);
+    std::vector<int> devices = a.devices.empty() ? std::vector<int>{a.device} : a.devices;
+    const size_t n_dev = devices.size();
+    const size_t n_values = (size_t)rs.render.width * rs.render.height * 3;
+    std::vector<uint8_t> image(n_values);
     rrt_stats stats;
+    std::memset(&stats, 0, sizeof(stats));
     const auto t_render = std::chrono::steady_clock::now();
-    int rc = rrt_render(backend, scene, &rs.render, &rs.post, image.data(), &stats);
+
+    // One host thread per GPU, each with its own scene and backend handle (handles are not shared
+    // between threads).  GPU g traces sample indices [begin + g n / G, begin + (g + 1) n / G) of every
+    // pixel with the same seed -- the stratified permutations are keyed on (seed, pixel, dimension), so
+    // the shards together visit each stratum once -- into a host accumulator of its own.
+    const uint64_t s_begin = rs.render.sample_begin, s_count = rs.render.sample_end - rs.render.sample_begin;
+    std::vector<std::vector<float>> sums(n_dev);
+    std::vector<rrt_stats> part(n_dev);
+    std::vector<std::string> errors(n_dev);
+    auto worker = [&](size_t g) {
+        rrt_render_desc d = rs.render;
+        d.sample_begin = s_begin + s_count * g / n_dev;
+        d.sample_end = s_begin + s_count * (g + 1) / n_dev;
+        std::memset(&part[g], 0, sizeof(rrt_stats));
+        if (d.sample_end == d.sample_begin) return;  // more GPUs than samples
+        sums[g].assign(n_values, 0.f);
+        rrt_scene_desc desc = sc.desc();
+        rrt_scene* scene = nullptr;
+        rrt_backend* backend = nullptr;
+        if (rrt_scene_create(&desc, &scene) != RRT_OK || rrt_backend_create("hip", devices[g], &backend) != RRT_OK ||
+            rrt_render_accumulate(backend, scene, &d, sums[g].data(), &part[g]) != RRT_OK)
+            errors[g] = rrt_last_error();  // thread-local in the library
+        rrt_backend_destroy(backend);
+        rrt_scene_destroy(scene);
+    };
+    if (n_dev == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (size_t g = 0; g < n_dev; ++g) threads.emplace_back(worker, g);
+        for (std::thread& t : threads) t.join();
+    }
+    for (size_t g = 0; g < n_dev; ++g)
+        if (!errors[g].empty()) throw std::runtime_error("GPU " + std::to_string(devices[g]) + ": " + errors[g]);
+    std::vector<float> total(n_values, 0.f);
+    for (size_t g = 0; g < n_dev; ++g) {
+        if (sums[g].empty()) continue;
+        for (size_t i = 0; i < n_values; ++i) total[i] += sums[g][i];
+        stats.samples += part[g].samples;
+        stats.rays += part[g].rays;
+        stats.prim_tests += part[g].prim_tests;
+        stats.node_tests += part[g].node_tests;
+        stats.nonfinite += part[g].nonfinite;
+        stats.kernel_ms = std::max(stats.kernel_ms, part[g].kernel_ms);
+    }
+    {   // mean -> tone map -> gamma -> white balance -> u8 on the first GPU; the divisor is samples_per_pixel
+        // even where RandomSampler traced one sample more (src/sampler.rs:48-55, src/renderer.rs:128)
+        rrt_backend* backend = nullptr;
+        RRT_CALL(rrt_backend_create("hip", devices[0], &backend));
+        int rc = rrt_postprocess(backend, total.data(), rs.render.spp, &rs.post, rs.render.width, rs.render.height, image.data());
+        std::string err = rc == RRT_OK ? "" : rrt_last_error();
+        rrt_backend_destroy(backend);
+        if (rc != RRT_OK) throw std::runtime_error("rrt_postprocess: " + err);
+    }
     const double render_s = seconds_since(t_render);
-    std::string err = rc == RRT_OK ? "" : rrt_last_error();
-    rrt_backend_destroy(backend);
-    rrt_scene_destroy(scene);
-    if (rc != RRT_OK) throw std::runtime_error("rrt_render: " + err);
     host::save_image(a.output, image.data(), rs.render.width, rs.render.height);
     const double total_s = seconds_since(t_start);
     std::fprintf(stderr, "rendered %ux%u, %llu samples, %llu rays in %.3f s (kernels %.3f s): %.1f Msamples/s; image saved to %s\n",
@@ -181,10 +242,10 @@ int run(const Args& a) {
         FILE* f = std::fopen(a.stats_json.c_str(), "w");
         if (!f) throw std::runtime_error("cannot write " + a.stats_json);
         std::fprintf(f,
-                     "{\"width\": %u, \"height\": %u, \"spp\": %u, \"n_prims\": %zu, \"n_objects\": %zu, \"samples\": %llu, "
+                     "{\"n_gpus\": %zu, \"width\": %u, \"height\": %u, \"spp\": %u, \"n_prims\": %zu, \"n_objects\": %zu, \"samples\": %llu, "
                      "\"rays\": %llu, \"prim_tests\": %llu, \"node_tests\": %llu, \"nonfinite\": %llu, \"load_s\": %.6f, "
                      "\"render_s\": %.6f, \"kernel_s\": %.6f, \"total_s\": %.6f}\n",
-                     rs.render.width, rs.render.height, rs.render.spp, sc.prims.size(), sc.materials.size(),
+                     n_dev, rs.render.width, rs.render.height, rs.render.spp, sc.prims.size(), sc.materials.size(),
                      (unsigned long long)stats.samples, (unsigned long long)stats.rays, (unsigned long long)stats.prim_tests,
                      (unsigned long long)stats.node_tests, (unsigned long long)stats.nonfinite, t_load, render_s,
                      stats.kernel_ms / 1e3, total_s);

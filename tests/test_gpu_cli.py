@@ -83,3 +83,26 @@ def test_report_harness(tmp_path):
         assert e["returncode"] == 0 and (out / t["dir"] / e["image"]).exists() and e["stats"]["samples"] == 96 * 64 * 64
     html = (out / "report.html").read_text()
     assert "cornell box@Stratified Sampler x 64spp@96 x 64" in html and "time cost" in html
+
+
+def test_cli_splits_samples_over_gpus(tmp_path):
+    """--devices: one host thread per listed GPU, sample-index shards, host-side sum.  Listing GPU 0 three
+    times exercises that path on a one-GPU box; the image must be the single-GPU image."""
+    from PIL import Image
+    scene = os.path.join(ROOT, "configs", "cornell_box", "scene.toml")
+    rc_path = tmp_path / "r.toml"
+    rc_path.write_text(RENDER.format(sampler="Stratified", strata="x_strata = 8\ny_strata = 8", wb=""))
+    outs = []
+    for name, extra in (("one", []), ("three", ["--devices", "0,0,0"])):
+        out, stats = tmp_path / f"{name}.png", tmp_path / f"{name}.json"
+        r = subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(out), "--stats-json", str(stats), *extra],
+                           capture_output=True, text=True, timeout=120, cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+        outs.append((np.asarray(Image.open(out).convert("RGB")).astype(int), json.load(open(stats))))
+    (img1, st1), (img3, st3) = outs
+    assert st3["n_gpus"] == 3 and st1["n_gpus"] == 1
+    assert st1["samples"] == st3["samples"] and st1["rays"] == st3["rays"]
+    assert np.abs(img1 - img3).max() <= 1 and np.mean(img1 != img3) < 0.01
+    r = subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(tmp_path / "x.png"), "--devices", "0,7"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 101 and "GPU 7" in r.stderr
