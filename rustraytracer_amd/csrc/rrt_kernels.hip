@@ -68,9 +68,22 @@ intersect_kernel(SceneView<R> sv, size_t n, const double* __restrict__ a, const 
 // trip and (almost) all 64 lanes are live in every scan; the expensive sampler
 // code (hash, stratum permutation) runs once per trip at full occupancy instead
 // of once for ray generation and once for scattering.
-template <typename R, bool BVH>
+//
+// LDS_TABLES: the shading tables (ShadeRec per primitive, MatRec per object) of a scene with at most
+// FUSED_LDS_PRIMS primitives are copied into LDS once per block, so the two dependent gathers of
+// every bounce (primitive -> surface, object -> material) have LDS latency.
+constexpr int FUSED_LDS_PRIMS = 64;
+
+template <typename R, bool BVH, bool LDS_TABLES>
 __global__ void __launch_bounds__(256)
 render_fused(SceneView<R> sv, RenderParams rp) {
+    __shared__ ShadeRec<R> s_shade[LDS_TABLES ? FUSED_LDS_PRIMS : 1];
+    __shared__ MatRec<R> s_mats[LDS_TABLES ? FUSED_LDS_PRIMS : 1];
+    if (LDS_TABLES) {
+        for (int i = threadIdx.x; i < sv.n_prims; i += 256) s_shade[i] = sv.shade[i];
+        for (int i = threadIdx.x; i < sv.n_objects; i += 256) s_mats[i] = sv.mats[i];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n_pixels = rp.width * rp.height;
 
@@ -112,7 +125,11 @@ render_fused(SceneView<R> sv, RenderParams rp) {
 #ifdef RRT_EXP_NOSHADE
             acc.x += t; acc.y += (R)g;
 #else
-            if (g >= 0) mode = process_hit<R>(sv, rp, path, g, t, acc, n, m, bad, counted);
+            if (g >= 0) {
+                const ShadeRec<R> sh = LDS_TABLES ? s_shade[g] : sv.shade[g];
+                m = LDS_TABLES ? s_mats[sh.object_id] : sv.mats[sh.object_id];
+                mode = process_hit<R>(rp, path, sh, m, t, acc, n, bad, counted);
+            }
 #endif
         }
         c_nonfinite += (uint32_t)__popcll(__ballot(bad));
@@ -299,10 +316,13 @@ static hipError_t launch_render_fused_t(const SceneView<R>& sv, bool bvh, const 
                                         hipStream_t stream) {
     // RRT_DEBUG_LDS_BYTES: occupancy experiments only (unused dynamic LDS caps the blocks per CU)
     static const size_t lds = [] { const char* e = getenv("RRT_DEBUG_LDS_BYTES"); return e ? (size_t)atol(e) : (size_t)0; }();
+    const bool tables = sv.n_prims <= FUSED_LDS_PRIMS && sv.n_objects <= FUSED_LDS_PRIMS;
     if (bvh)
-        hipLaunchKernelGGL((render_fused<R, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
+        hipLaunchKernelGGL((render_fused<R, true, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
+    else if (tables)
+        hipLaunchKernelGGL((render_fused<R, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
     else
-        hipLaunchKernelGGL((render_fused<R, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
+        hipLaunchKernelGGL((render_fused<R, false, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
     return hipGetLastError();
 }
 hipError_t launch_render_fused(const SceneView<float>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {

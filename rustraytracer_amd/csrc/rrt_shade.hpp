@@ -62,11 +62,11 @@ enum : int { MODE_NEW = 0 };
 // A path at its last permitted vertex (depth + 1 == max_depth) ends here: the
 // reference still scatters it (utils.rs:66-87) and then leaves its loop, so the
 // new ray is never traced and nothing it computed can reach the image.
+// `sh` is the ShadeRec of the primitive that was hit and `m` the MatRec of its object (the caller
+// fetches them: from HBM, or from the copy a kernel keeps in LDS for a small scene).
 template <typename R>
-RRT_DEV int process_hit(const SceneView<R>& sv, const RenderParams& rp, Path<R>& p, int g, R t, V3<R>& acc,
-                        V3<R>& n, MatRec<R>& m, bool& bad, int& counted) {
-    const ShadeRec<R> sh = sv.shade[g];
-    m = sv.mats[sh.object_id];
+RRT_DEV int process_hit(const RenderParams& rp, Path<R>& p, const ShadeRec<R>& sh, const MatRec<R>& m, R t, V3<R>& acc,
+                        V3<R>& n, bool& bad, int& counted) {
     V3<R> P = mk<R>(p.o.x + t * p.d.x, p.o.y + t * p.d.y, p.o.z + t * p.d.z);
     n = mk<R>(sh.nx, sh.ny, sh.nz);
     if (sh.type == PRIM_SPHERE) {  // (point - center) / radius, src/shapes/sphere.rs:87

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
 // Tree traversal lengths differ by an order of magnitude between the rays of one wave (a ray that
 // only sees the room's walls is done after a few nodes, one that grazes a mesh visits hundreds), so
 // one-ray-per-lane leaves most lanes idle most of the time.  Here a wave is persistent: it walks its
-// own blocks of 64 rays (block b belongs to wave b % n_waves, no shared counter) and hands the next
+// own blocks of 64 rays (every n_waves-th block, no shared counter) and hands the next
 // rays to lanes as they finish, whenever at least WF_REFILL_MIN lanes are idle.
 constexpr int WF_REFILL_MIN = 8;
 
@@ -111,9 +111,30 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
         wp.ctl->count[parity ^ 1] = 0;
         wp.ctl->rays += n_in;
     }
-    const uint32_t n_waves = gridDim.x * (BVH_BLOCK / 64);
-    uint32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (BVH_BLOCK / 64) + (threadIdx.x >> 6));
-    if (blockIdx.x * (uint32_t)BVH_BLOCK >= n_in) return;  // the block's first blocks of rays do not exist
+    // Which blocks of 64 rays this wave walks: blk, blk + stride, ... below blk_end.
+    const uint32_t n_ray_blocks = (n_in + 63u) / 64u;
+    uint32_t blk, stride, blk_end;
+#ifdef RRT_EXP_XCD_REGIONS
+    if ((gridDim.x & 7u) == 0u) {
+        // workgroups b and b + 8 share an XCD and its L2: give each XCD one contiguous eighth of the queue
+        const uint32_t per_region = (n_ray_blocks + 7u) / 8u;
+        const uint32_t region = blockIdx.x & 7u;
+        stride = (gridDim.x >> 3) * (BVH_BLOCK / 64);
+        blk = region * per_region + (blockIdx.x >> 3) * (BVH_BLOCK / 64) + (threadIdx.x >> 6);
+        blk_end = region * per_region + per_region;
+        blk_end = blk_end < n_ray_blocks ? blk_end : n_ray_blocks;
+    } else
+#endif
+    {
+        stride = gridDim.x * (BVH_BLOCK / 64);
+        blk = blockIdx.x * (BVH_BLOCK / 64) + (threadIdx.x >> 6);
+        blk_end = n_ray_blocks;
+    }
+    blk = __builtin_amdgcn_readfirstlane(blk);
+    {   // a block none of whose waves has a first block of rays has nothing to do
+        const uint32_t first_wave_blk = blk - (threadIdx.x >> 6);
+        if (first_wave_blk >= blk_end) return;
+    }
     if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
     __syncthreads();
     uint32_t off = 0;
@@ -140,11 +161,12 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                 q.hit[mine] = make_float2(w.acc.t, __int_as_float(g >= 0 ? g : WF_MISS));
                 have = false;
             }
-            if ((unsigned long long)blk * 64ull < (unsigned long long)n_in) {
+            if (blk < blk_end) {
                 const uint32_t k = off + lane_rank(idle_mask);
+                const uint32_t next_blk = blk + stride;  // n_in < 2^32, so block numbers stay far below 2^32
                 const unsigned long long idx64 =
-                    k < 64u ? (unsigned long long)blk * 64ull + k : ((unsigned long long)blk + n_waves) * 64ull + (k - 64u);
-                if (idle && idx64 < (unsigned long long)n_in) {
+                    k < 64u ? (unsigned long long)blk * 64ull + k : (unsigned long long)next_blk * 64ull + (k - 64u);
+                if (idle && idx64 < (unsigned long long)n_in && (k < 64u || next_blk < blk_end)) {
                     mine = (uint32_t)idx64;
                     const float4 a = q.o_dx[mine];
                     const float2 b = q.dyz[mine];
@@ -156,7 +178,7 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                 off += n_idle;
                 if (off >= 64u) {
                     off -= 64u;
-                    blk += n_waves;
+                    blk += stride;
                 }
             }
             if (__ballot(w.node != BVH_DONE) == 0ull) break;
@@ -259,7 +281,9 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity) {
             path.smp.dim = (s.y >> 20) & 7u;
             path.depth = s.y >> 23;
             V3<R> acc = mk<R>(0, 0, 0);
-            mode = process_hit<R>(sv, rp, path, g, h.x, acc, n, m, bad, counted);
+            const ShadeRec<R> sh = sv.shade[g];
+            m = sv.mats[sh.object_id];
+            mode = process_hit<R>(rp, path, sh, m, h.x, acc, n, bad, counted);
             // only an emitter adds radiance, and it ends the path: at most one add per sample
             if (acc.x != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 0], acc.x);
             if (acc.y != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 1], acc.y);
