@@ -30,13 +30,20 @@ RRT_DEV R fresnel(R cos_i, R eta_i, R eta_t) {
     return (r_ortho * r_ortho + r_parallel * r_parallel) * R(0.5);
 }
 
-// spherical_to_world over local_coordinate_system (src/math.rs:162-179) with
-// sin/cos of theta and phi already known.
+// spherical_to_world (src/math.rs:174-179) with sin/cos of theta and phi already known, over an
+// orthonormal basis around the unit vector w.  The reference builds its basis with two cross
+// products and two normalisations (local_coordinate_system, src/math.rs:162-172); both lobes that
+// use it (cosine-weighted, Phong) are symmetric in phi and phi is uniform, so the distribution of
+// the sampled direction does not depend on which basis is taken.  This one is the branch-free
+// construction of Duff et al. ("Building an Orthonormal Basis, Revisited", JCGT 2017): one
+// reciprocal and a dozen multiply-adds.
 template <typename R>
 RRT_DEV V3<R> to_world(R sin_t, R cos_t, R sin_p, R cos_p, V3<R> w) {
-    V3<R> a = Num<R>::abs(w.x) > R(0.9) ? mk<R>(0, 1, 0) : mk<R>(1, 0, 0);
-    V3<R> u = normalize(cross(w, a));
-    V3<R> v = normalize(cross(w, u));
+    const R sign = w.z >= R(0) ? R(1) : R(-1);
+    const R a = R(-1) * Num<R>::rcp(sign + w.z);
+    const R b = w.x * w.y * a;
+    const V3<R> u = mk<R>(R(1) + sign * w.x * w.x * a, sign * b, -sign * w.x);
+    const V3<R> v = mk<R>(b, sign + w.y * w.y * a, -w.y);
     R cu = sin_t * cos_p, cv = sin_t * sin_p;
     return mk<R>(u.x * cu + v.x * cv + w.x * cos_t, u.y * cu + v.y * cv + w.y * cos_t,
                  u.z * cu + v.z * cv + w.z * cos_t);
