@@ -150,8 +150,8 @@ def main():
     lo, hi = D.shard_range(rc.spp, rank, world)
     pipeline = {"auto": api.PIPELINE_AUTO, "fused": api.PIPELINE_FUSED, "wavefront": api.PIPELINE_WAVEFRONT}[args.pipeline]
     desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline)
-    # what AUTO resolves to (include/rrt.h): the tree for more than 48 primitives, and with it the wavefront pipeline
-    use_tree = flat.n_prims > 48
+    # what AUTO resolves to (include/rrt.h): the tree for more than 128 primitives, and with it the wavefront pipeline
+    use_tree = flat.n_prims > 128
     wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and use_tree)
     post = rc.post_desc()
     acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32, device="cuda")

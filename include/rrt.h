@@ -62,7 +62,8 @@ typedef enum rrt_sampler_type { RRT_SAMPLER_RANDOM = 0, RRT_SAMPLER_STRATIFIED =
 typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_precision;
 
 /* How closest-hit walks the primitives.  AUTO = wave-uniform linear scan for
- * small scenes, LBVH (+ linear scan of the unbounded planes) otherwise. */
+ * scenes of up to 128 primitives (where it is the faster of the two), LBVH
+ * (+ linear scan of the unbounded planes) otherwise. */
 typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2 } rrt_accel;
 
 /* Which kernel organisation renders.  FUSED keeps a path in registers for

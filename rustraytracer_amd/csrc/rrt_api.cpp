@@ -292,8 +292,10 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
-// Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO.
-const size_t kAutoBvhThreshold = 48;
+// Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO.  Measured crossover on
+// triangle meshes (tools/gpu_crossover.py): the scan renders 92 primitives at 7.2 Grays/s and 184 at
+// 3.8, the tree + wavefront pipeline stays at 5.7.
+const size_t kAutoBvhThreshold = 128;
 // Subtrees of at most this many primitives are folded into one leaf.  A traversal step costs one
 // 64-byte fetch whether it reads a node or a primitive; 2 minimises their sum on triangle meshes.
 const int kBvhLeafMax = 2;
