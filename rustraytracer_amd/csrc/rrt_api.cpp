@@ -238,9 +238,9 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view,
         }
         runs[runs.size() - 2] += 1;
     }
-    std::vector<rrt::PairRec<R>> pairs;  // parallelogram runs, two records side by side
+    std::vector<rrt::PairRec<R>> pairs;  // parallelogram and triangle runs, two records side by side
     for (size_t r = 0; r < runs.size(); r += 4) {
-        if (runs[r] != rrt::PRIM_PGRAM) continue;
+        if (runs[r] != rrt::PRIM_PGRAM && runs[r] != rrt::PRIM_TRIANGLE) continue;
         runs[r + 3] = (int32_t)pairs.size();
         for (int k = 0; k < runs[r + 2]; k += 2) {
             rrt::PairRec<R> pr;

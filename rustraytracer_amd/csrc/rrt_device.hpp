@@ -368,12 +368,12 @@ RRT_DEV void scan_run(const PrimRec<R> RRT_CONSTANT* prims, int first, int count
     }
 }
 
-// Two parallelograms per step with packed FP32 arithmetic: component 0 of every R2 belongs
+// Two parallelograms (or two triangles) per step with packed FP32 arithmetic: component 0 of every R2 belongs
 // to the first record of the pair, component 1 to the second.  The dot products, t, the hit
 // point and both coefficients are packed (one issue slot for two primitives); reciprocal,
 // |x|, min3 and the selects have no packed form.  The second record is judged against the
 // closest hit as updated by the first, exactly as in a sequential scan.
-template <typename R>
+template <typename R, int TYPE>
 RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int count, V3<R> o, V3<R> d,
                             R& best_t, int& best_g) {
     typedef R R2 __attribute__((ext_vector_type(2)));
@@ -393,18 +393,32 @@ RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int
         R2 a = ((f[4] * px + f[5] * py) + f[6] * pz) + f[7];
         R2 b = ((f[8] * px + f[9] * py) + f[10] * pz) + f[11];
         R2 tm = t - Num<R>::tmin();
-        // |a| <= 1/2 <=> 1/4 - a^2 >= 0 exactly (the square of the f32/f64 next to 1/2 rounds to the
-        // proper side of 1/4), and the square form is one packed FMA for both records
-        R2 qa = R(0.25) - a * a;
-        R2 qb = R(0.25) - b * b;
-        R h0 = min3((R)qa.x, (R)qb.x, Num<R>::abs(nd.x) - Num<R>::eps());
-        const bool ok0 = min3(h0, tm.x, headroom(best_t, (R)t.x)) >= R(0);
-        best_t = ok0 ? t.x : best_t;
-        best_g = ok0 ? first + 2 * k : best_g;
-        R h1 = min3((R)qa.y, (R)qb.y, Num<R>::abs(nd.y) - Num<R>::eps());
-        const bool ok1 = min3(h1, tm.y, headroom(best_t, (R)t.y)) >= R(0);
-        best_t = ok1 ? t.y : best_t;
-        best_g = ok1 ? first + 2 * k + 1 : best_g;
+        if (TYPE == PRIM_PGRAM) {
+            // |a| <= 1/2 <=> 1/4 - a^2 >= 0 exactly (the square of the f32/f64 next to 1/2 rounds to the
+            // proper side of 1/4), and the square form is one packed FMA for both records
+            R2 qa = R(0.25) - a * a;
+            R2 qb = R(0.25) - b * b;
+            R h0 = min3((R)qa.x, (R)qb.x, Num<R>::abs(nd.x) - Num<R>::eps());
+            const bool ok0 = min3(h0, tm.x, headroom(best_t, (R)t.x)) >= R(0);
+            best_t = ok0 ? t.x : best_t;
+            best_g = ok0 ? first + 2 * k : best_g;
+            R h1 = min3((R)qa.y, (R)qb.y, Num<R>::abs(nd.y) - Num<R>::eps());
+            const bool ok1 = min3(h1, tm.y, headroom(best_t, (R)t.y)) >= R(0);
+            best_t = ok1 ? t.y : best_t;
+            best_g = ok1 ? first + 2 * k + 1 : best_g;
+        } else {
+            // triangle: u, v >= 0 and u + v <= 1 (u <= 1 follows: the rounded sum is never below u
+            // when v >= 0), and an OPEN t interval
+            R2 rest = R(1) - (a + b);
+            R h0 = fmin(min3((R)a.x, (R)b.x, (R)rest.x), Num<R>::abs(nd.x) - Num<R>::eps());
+            const bool ok0 = (h0 >= R(0)) && (fmin((R)tm.x, headroom(best_t, (R)t.x)) > R(0));
+            best_t = ok0 ? t.x : best_t;
+            best_g = ok0 ? first + 2 * k : best_g;
+            R h1 = fmin(min3((R)a.y, (R)b.y, (R)rest.y), Num<R>::abs(nd.y) - Num<R>::eps());
+            const bool ok1 = (h1 >= R(0)) && (fmin((R)tm.y, headroom(best_t, (R)t.y)) > R(0));
+            best_t = ok1 ? t.y : best_t;
+            best_g = ok1 ? first + 2 * k + 1 : best_g;
+        }
     }
 }
 
@@ -423,9 +437,9 @@ RRT_DEV void scan_linear(const SceneView<R>& sv, V3<R> o, V3<R> d, R& best_t, in
         switch (type) {
         case PRIM_SPHERE: scan_run<R, PRIM_SPHERE>(prims, first, count, o, d, best_t, best_g); break;
         case PRIM_PLANE: scan_run<R, PRIM_PLANE>(prims, first, count, o, d, best_t, best_g); break;
-        case PRIM_TRIANGLE: scan_run<R, PRIM_TRIANGLE>(prims, first, count, o, d, best_t, best_g); break;
+        case PRIM_TRIANGLE: scan_run_pairs<R, PRIM_TRIANGLE>(as_constant(sv.pairs) + runs[4 * r + 3], first, count, o, d, best_t, best_g); break;
         case PRIM_QUAD: scan_run<R, PRIM_QUAD>(prims, first, count, o, d, best_t, best_g); break;
-        default: scan_run_pairs<R>(as_constant(sv.pairs) + runs[4 * r + 3], first, count, o, d, best_t, best_g); break;
+        default: scan_run_pairs<R, PRIM_PGRAM>(as_constant(sv.pairs) + runs[4 * r + 3], first, count, o, d, best_t, best_g); break;
         }
     }
 }

@@ -36,7 +36,7 @@ struct PrimRec {
     int32_t type;
 };
 
-// Two parallelograms of one run side by side: g[k] = (f[k] of the first, f[k] of the second),
+// Two parallelograms (or two triangles) of one run side by side: g[k] = (f[k] of the first, f[k] of the second),
 // k = 0..11.  A wave-uniform pair lands in 24 SGPRs as 12 aligned pairs, which is the operand
 // shape of the packed FP32 instructions (v_pk_fma_f32 & co. do two FMAs per lane per issue
 // slot).  An odd run is padded with an all-zero record, which every ray rejects (n . d = 0).
@@ -128,7 +128,7 @@ struct SceneView {
     int32_t n_prims;
     int32_t n_objects;
     const int32_t* runs;       // n_runs x (type, first, count, first pair): maximal runs of equal PrimRec.type
-    const PairRec<R>* pairs;   // PairRec table of the parallelogram runs
+    const PairRec<R>* pairs;   // PairRec table of the parallelogram and triangle runs
     int32_t n_runs;
     int32_t pad0;
     // acceleration structure (n_bvh_prims == 0: linear scan over all prims)
