@@ -552,10 +552,11 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
 }
 
 // ------------------------------------------------------------------ wavefront pipeline
-// Paths per queue (56 bytes per path and queue).  A trip of the linear-scan pipeline costs two
-// kernel launches and streams the queue through HBM once; the tree kernel is persistent and ends
-// every trip with a tail of half-empty waves, so it wants several rays per lane and trip.
-const uint32_t kWfCapacityLinear = 1u << 22;
+// Paths per queue (56 bytes per path and queue).  Every trip costs one or two kernel launches with
+// their ramp-up and tail, and the persistent tree kernel ends every trip with half-empty waves, so
+// both want many rays per lane and trip: 16 Mi paths measured best for both (Cornell box through the
+// one-kernel-per-trip pipeline: 7.8 Gsamples/s at 1 Mi, 10.4 at 4 Mi, 11.2 at 16 Mi).
+const uint32_t kWfCapacityLinear = 1u << 24;
 const uint32_t kWfCapacityTree = 1u << 24;
 
 int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity) {
@@ -625,15 +626,28 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
     const uint64_t sure = total / capacity;
     const uint64_t check_every = 4;
     rrt::WfControl ctl;
-    int parity = 0;
-    for (uint64_t trip = 0;; ++trip) {
-        HIP_TRY(rrt::wf_launch_shade(sv, rp, wp, parity, be->stream));
-        parity ^= 1;
-        HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, be->n_cu * 8, be->stream));
-        if (trip >= sure && (trip - sure) % check_every == 0) {
-            HIP_TRY(hipMemcpyAsync(&ctl, wp.ctl, sizeof(ctl), hipMemcpyDeviceToHost, be->stream));
-            HIP_TRY(hipStreamSynchronize(be->stream));
-            if (ctl.count[parity] == 0) break;
+    if (!use_bvh) {
+        // linear-scan scenes: one kernel per trip (closest hit fused into the shade kernel); the last trip's
+        // output count is count[(trip + 1) % 3]
+        for (uint64_t trip = 0;; ++trip) {
+            HIP_TRY(rrt::wf_launch_shade_scan(sv, rp, wp, trip, be->stream));
+            if (trip >= sure && (trip - sure) % check_every == 0) {
+                HIP_TRY(hipMemcpyAsync(&ctl, wp.ctl, sizeof(ctl), hipMemcpyDeviceToHost, be->stream));
+                HIP_TRY(hipStreamSynchronize(be->stream));
+                if (ctl.count[(trip + 1) % 3] == 0) break;
+            }
+        }
+    } else {
+        int parity = 0;
+        for (uint64_t trip = 0;; ++trip) {
+            HIP_TRY(rrt::wf_launch_shade(sv, rp, wp, parity, be->stream));
+            parity ^= 1;
+            HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, be->n_cu * 8, be->stream));
+            if (trip >= sure && (trip - sure) % check_every == 0) {
+                HIP_TRY(hipMemcpyAsync(&ctl, wp.ctl, sizeof(ctl), hipMemcpyDeviceToHost, be->stream));
+                HIP_TRY(hipStreamSynchronize(be->stream));
+                if (ctl.count[parity] == 0) break;
+            }
         }
     }
     std::vector<unsigned long long> rows(rows_bytes / sizeof(unsigned long long));

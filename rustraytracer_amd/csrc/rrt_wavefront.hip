@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(256) wf_init(RenderParams rp, WfParams wp) {
     }
     if (i == 0) {
         wp.ctl->count[0] = wp.capacity;
-        wp.ctl->count[1] = 0;
+        wp.ctl->count[1] = wp.ctl->count[2] = wp.ctl->count[3] = 0;
         wp.ctl->rays = 0;
     }
 }
@@ -230,22 +230,33 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
 // the lane either scatters its path or, if it holds none any more, starts the next camera sample of
 // its wave's cursor.  Every lane that ends the trip with a ray writes it to the output queue at
 //   block base (one atomicAdd per block) + rays of the earlier waves of the block + rank in the wave.
-__global__ void __launch_bounds__(WF_SHADE_BLOCK)
-wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity) {
+//
+// FUSE_HIT (scenes whose closest hit is the wave-uniform linear scan): the scan runs here, on the ray
+// just read, instead of in a kernel of its own -- no hit queue, the ray is read once, and the scan's
+// arithmetic overlaps the queue traffic.  The live counts then rotate through three words: this
+// trip reads count[c_in], adds to count[c_out] and clears the word the NEXT trip will add to (no
+// block of this launch touches that one).
+template <bool FUSE_HIT, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in, int c_out, int c_clear, int first_trip) {
     typedef float R;
-    constexpr int WAVES = WF_SHADE_BLOCK / 64;
+    constexpr int WAVES = BLOCK / 64;
     __shared__ BlockCounters s_ctr;
     __shared__ uint32_t s_wave_rays[WAVES];
     __shared__ uint32_t s_base;
 
-    const uint32_t idx = blockIdx.x * (uint32_t)WF_SHADE_BLOCK + threadIdx.x;
+    const uint32_t idx = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gwave = __builtin_amdgcn_readfirstlane(idx >> 6);
     const WfQueue& qi = wp.q[parity];
     const WfQueue& qo = wp.q[parity ^ 1];
-    const uint32_t n_in = wp.ctl->count[parity];
+    const uint32_t n_in = wp.ctl->count[c_in];
     const uint32_t n_pixels = rp.width * rp.height;
+    if (FUSE_HIT && blockIdx.x == 0 && threadIdx.x == 0) {
+        wp.ctl->count[c_clear] = 0;
+        if (!first_trip) wp.ctl->rays += n_in;
+    }
 
     if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
     __syncthreads();
@@ -262,16 +273,36 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity) {
     m.r = m.g = m.b = m.param = R(0);
     m.type = 0;
 
-    if (idx < n_in) {
-        const float2 h = qi.hit[idx];
-        const int g = __float_as_int(h.y);
-        if (g >= 0) {
-            const float4 a = qi.o_dx[idx];
-            const float2 b = qi.dyz[idx];
-            const float4 c = qi.beta_pix[idx];
-            const uint2 s = qi.smp[idx];
+    int g = WF_EMPTY;
+    float t_hit = 0.f;
+    if (FUSE_HIT) {
+        // every lane of a wave that holds at least one ray runs the scan (wave-uniform loads)
+        const bool have = idx < n_in && !first_trip;
+        if (__ballot(have)) {
+            const uint32_t j = have ? idx : 0u;
+            const float4 a = qi.o_dx[j];
+            const float2 b = qi.dyz[j];
             path.o = mk<R>(a.x, a.y, a.z);
             path.d = mk<R>(a.w, b.x, b.y);
+            HitCounters hc{0, 0};
+            const int found = closest_hit<float, false>(sv, path.o, path.d, t_hit, hc);
+            g = have ? (found >= 0 ? found : WF_MISS) : WF_EMPTY;
+        }
+    } else if (idx < n_in) {
+        const float2 h = qi.hit[idx];
+        t_hit = h.x;
+        g = __float_as_int(h.y);
+    }
+    {
+        if (g >= 0) {
+            if (!FUSE_HIT) {
+                const float4 a = qi.o_dx[idx];
+                const float2 b = qi.dyz[idx];
+                path.o = mk<R>(a.x, a.y, a.z);
+                path.d = mk<R>(a.w, b.x, b.y);
+            }
+            const float4 c = qi.beta_pix[idx];
+            const uint2 s = qi.smp[idx];
             path.beta = mk<R>(c.x, c.y, c.z);
             pixel = __float_as_uint(c.w);
             path.smp.pixkey = pixel_key(rp.seed_lo, rp.seed_hi, pixel);
@@ -283,7 +314,7 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity) {
             V3<R> acc = mk<R>(0, 0, 0);
             const ShadeRec<R> sh = sv.shade[g];
             m = sv.mats[sh.object_id];
-            mode = process_hit<R>(rp, path, sh, m, h.x, acc, n, bad, counted);
+            mode = process_hit<R>(rp, path, sh, m, t_hit, acc, n, bad, counted);
             // only an emitter adds radiance, and it ends the path: at most one add per sample
             if (acc.x != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 0], acc.x);
             if (acc.y != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 1], acc.y);
@@ -369,7 +400,7 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity) {
     if (threadIdx.x == 0) {
         uint32_t total = 0;
         for (int w = 0; w < WAVES; ++w) total += s_wave_rays[w];
-        s_base = total ? atomicAdd(&wp.ctl->count[parity ^ 1], total) : 0u;
+        s_base = total ? atomicAdd(&wp.ctl->count[c_out], total) : 0u;
     }
     __syncthreads();
     if (have_ray) {
@@ -406,8 +437,17 @@ hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfP
 
 hipError_t wf_launch_shade(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp, int parity,
                            hipStream_t stream) {
-    hipLaunchKernelGGL(wf_shade, dim3(wp.capacity / (uint32_t)WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, stream, sv,
-                       rp, wp, parity);
+    hipLaunchKernelGGL((wf_shade<false, WF_SHADE_BLOCK>), dim3(wp.capacity / (uint32_t)WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, stream,
+                       sv, rp, wp, parity, parity, parity ^ 1, 0, 0);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_shade_scan(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp,
+                                unsigned long long trip, hipStream_t stream) {
+    // 512 threads: with the scan's scalar registers a SIMD holds 7 waves, i.e. three blocks of 512 per CU but only one of 1024
+    hipLaunchKernelGGL((wf_shade<true, WF_SHADE_SCAN_BLOCK>), dim3(wp.capacity / (uint32_t)WF_SHADE_SCAN_BLOCK), dim3(WF_SHADE_SCAN_BLOCK), 0, stream,
+                       sv, rp, wp, (int)(trip & 1), (int)(trip % 3), (int)((trip + 1) % 3), (int)((trip + 2) % 3),
+                       trip == 0 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 // One trip handles every live path once:
 //   wf_closest_hit   ray queue -> hit queue            (Scene::intersect, src/scene.rs:35-47)
 //   wf_shade         ray + hit queue -> next ray queue (src/tracers/utils.rs:41-87, one loop body)
+// (for scenes small enough for the wave-uniform linear scan the two are one kernel, wf_shade<true>)
 // wf_shade also starts new camera samples in every lane that has no surviving path, so the queue
 // stays full until the render runs out of samples, and writes survivors and new paths densely
 // (wave64 ballot + lane rank inside a wave, one counter reservation per block).
@@ -27,8 +28,7 @@ enum : int { WF_MISS = -1, WF_EMPTY = -2 };
 constexpr uint32_t WF_MAX_DEPTH = 511;  // 9 bits of the packed sampler word
 
 struct WfControl {
-    uint32_t count[2];        // live paths in queue 0 / 1
-    uint32_t pad[2];
+    uint32_t count[4];        // live paths: count[parity] (two kernels per trip) or count[trip % 3] (one kernel per trip)
     unsigned long long rays;  // closest-hit queries so far
 };
 
@@ -52,6 +52,7 @@ struct WfParams {
 };
 
 constexpr int WF_SHADE_BLOCK = 1024;
+constexpr int WF_SHADE_SCAN_BLOCK = 512;
 constexpr int WF_HIT_BLOCK = 256;
 
 hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_t stream);
@@ -60,5 +61,8 @@ hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfP
                                  int persistent_blocks, hipStream_t stream);
 hipError_t wf_launch_shade(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp, int parity,
                            hipStream_t stream);
+// One kernel per trip for linear-scan scenes: closest hit + shade.  Trip t reads queue t & 1 and count[t % 3].
+hipError_t wf_launch_shade_scan(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp,
+                                unsigned long long trip, hipStream_t stream);
 
 }  // namespace rrt
