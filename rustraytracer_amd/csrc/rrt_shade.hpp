@@ -21,12 +21,12 @@ RRT_DEV V3<R> reflect(V3<R> v, V3<R> n) {
 
 template <typename R>
 RRT_DEV R fresnel(R cos_i, R eta_i, R eta_t) {
-    R ratio = eta_i / eta_t;
+    R ratio = eta_i * Num<R>::rcp(eta_t);  // (f32: v_rcp_f32, 1 ulp; an IEEE divide costs ten instructions)
     R sin2_t = ratio * ratio * (R(1) - cos_i * cos_i);
     if (sin2_t > R(1)) return R(1);
     R cos_t = Num<R>::sqrt(R(1) - sin2_t);
-    R r_ortho = (eta_t * cos_i - eta_i * cos_t) / (eta_t * cos_i + eta_i * cos_t);
-    R r_parallel = (eta_i * cos_i - eta_t * cos_t) / (eta_i * cos_i + eta_t * cos_t);
+    R r_ortho = (eta_t * cos_i - eta_i * cos_t) * Num<R>::rcp(eta_t * cos_i + eta_i * cos_t);
+    R r_parallel = (eta_i * cos_i - eta_t * cos_t) * Num<R>::rcp(eta_i * cos_i + eta_t * cos_t);
     return (r_ortho * r_ortho + r_parallel * r_parallel) * R(0.5);
 }
 
@@ -130,7 +130,8 @@ RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, cons
     } else if (mode == MAT_PHONG) {  // src/material.rs:104-142
         V3<R> refl = reflect(p.d, n);
         R s = m.param;
-        R cos_t = Num<R>::pow(u, R(1) / (s + R(1)));
+        R inv_s1 = Num<R>::rcp(s + R(1));
+        R cos_t = Num<R>::pow(u, inv_s1);
         R sin_t = Num<R>::sqrt(fmax(R(1) - cos_t * cos_t, R(0)));
         R sp, cp;
         Num<R>::sincos2pi(v, sp, cp);
@@ -138,7 +139,7 @@ RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, cons
         R c = dot(dir, refl);
         R pdf = Num<R>::pow(c, s) * (s + R(1)) * Num<R>::inv_pi() * R(0.5);
         if (!(pdf > Num<R>::eps())) return false;
-        R w = Num<R>::abs(dot(dir, n)) * (s + R(2)) / (s + R(1));
+        R w = Num<R>::abs(dot(dir, n)) * (s + R(2)) * inv_s1;
         p.beta = mk<R>(p.beta.x * m.r * w, p.beta.y * m.g * w, p.beta.z * m.b * w);
     } else if (mode == MAT_REFLECTOR) {  // src/material.rs:156-181
         dir = reflect(p.d, n);
@@ -149,7 +150,7 @@ RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, cons
         V3<R> on = inside ? mk<R>(-n.x, -n.y, -n.z) : n;
         R eta_i = inside ? m.param : R(1);
         R eta_t = inside ? R(1) : m.param;
-        R eta = eta_i / eta_t;
+        R eta = eta_i * Num<R>::rcp(eta_t);
         R cos_theta = -dot(p.d, on);
         R r = get_1d<R>(p.smp, rp, true);
         R F = fresnel<R>(cos_theta, eta_i, eta_t);
@@ -165,7 +166,7 @@ RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, cons
             R k = eta * cos_theta - cos_t2;
             dir = mk<R>(eta * p.d.x + k * on.x, eta * p.d.y + k * on.y, eta * p.d.z + k * on.z);
             pdf = R(1) - F;
-            w = R(1) / (eta * eta);
+            w = Num<R>::rcp(eta * eta);
         }
         if (pdf <= Num<R>::eps()) return false;
         if (Num<R>::abs(dot(dir, n)) < Num<R>::eps()) return false;
