@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(256) wf_init(RenderParams rp, WfParams wp) {
     if (i == 0) {
         wp.ctl->count[0] = wp.capacity;
         wp.ctl->count[1] = wp.ctl->count[2] = wp.ctl->count[3] = 0;
+        wp.ctl->dyn[0] = wp.ctl->dyn[1] = 0;
         wp.ctl->rays = 0;
     }
 }
@@ -97,8 +98,8 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
 // Tree traversal lengths differ by an order of magnitude between the rays of one wave (a ray that
 // only sees the room's walls is done after a few nodes, one that grazes a mesh visits hundreds), so
 // one-ray-per-lane leaves most lanes idle most of the time.  Here a wave is persistent: it walks its
-// own blocks of 64 rays (every n_waves-th block, no shared counter) and hands the next
-// rays to lanes as they finish, whenever at least WF_REFILL_MIN lanes are idle.
+// blocks of 64 rays and hands the next rays to lanes as they finish, whenever at least
+// WF_REFILL_MIN lanes are idle.
 constexpr int WF_REFILL_MIN = 8;
 
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
@@ -111,29 +112,33 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
         wp.ctl->count[parity ^ 1] = 0;
         wp.ctl->rays += n_in;
     }
-    // Which blocks of 64 rays this wave walks: blk, blk + stride, ... below blk_end.
+    // Which blocks of 64 rays this wave walks.  The first three quarters of the queue are dealt out
+    // statically (wave w takes blocks w, w + n_waves, ...: no shared counter); the last quarter is
+    // handed out block by block through an atomic counter, so that waves whose rays happened to be
+    // cheap help the others finish instead of idling (a third of the wave slots stood empty at the
+    // end of every trip with the static deal alone).
     const uint32_t n_ray_blocks = (n_in + 63u) / 64u;
-    uint32_t blk, stride, blk_end;
-#ifdef RRT_EXP_XCD_REGIONS
-    if ((gridDim.x & 7u) == 0u) {
-        // workgroups b and b + 8 share an XCD and its L2: give each XCD one contiguous eighth of the queue
-        const uint32_t per_region = (n_ray_blocks + 7u) / 8u;
-        const uint32_t region = blockIdx.x & 7u;
-        stride = (gridDim.x >> 3) * (BVH_BLOCK / 64);
-        blk = region * per_region + (blockIdx.x >> 3) * (BVH_BLOCK / 64) + (threadIdx.x >> 6);
-        blk_end = region * per_region + per_region;
-        blk_end = blk_end < n_ray_blocks ? blk_end : n_ray_blocks;
-    } else
-#endif
-    {
-        stride = gridDim.x * (BVH_BLOCK / 64);
-        blk = blockIdx.x * (BVH_BLOCK / 64) + (threadIdx.x >> 6);
-        blk_end = n_ray_blocks;
-    }
-    blk = __builtin_amdgcn_readfirstlane(blk);
-    {   // a block none of whose waves has a first block of rays has nothing to do
-        const uint32_t first_wave_blk = blk - (threadIdx.x >> 6);
-        if (first_wave_blk >= blk_end) return;
+    if (blockIdx.x * (uint32_t)(BVH_BLOCK / 64) >= n_ray_blocks) return;  // more waves than blocks of rays
+    const uint32_t stride = gridDim.x * (BVH_BLOCK / 64);
+    const uint32_t static_end = (n_ray_blocks - n_ray_blocks / 4u) / stride * stride;
+    if (blockIdx.x == 0 && threadIdx.x == 0) wp.ctl->dyn[parity ^ 1] = 0;  // the next trip's counter
+    uint32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (BVH_BLOCK / 64) + (threadIdx.x >> 6));
+    bool dynamic = false;
+    auto next_block = [&]() {  // wave-uniform
+        if (!dynamic) {
+            blk += stride;
+            if (blk < static_end) return;
+            dynamic = true;
+        }
+        uint32_t got = 0;
+        if ((threadIdx.x & 63u) == 0) got = atomicAdd(&wp.ctl->dyn[parity], 1u);
+        blk = static_end + __builtin_amdgcn_readfirstlane(got);
+    };
+    if (blk >= static_end) {
+        dynamic = true;
+        uint32_t got = 0;
+        if ((threadIdx.x & 63u) == 0) got = atomicAdd(&wp.ctl->dyn[parity], 1u);
+        blk = static_end + __builtin_amdgcn_readfirstlane(got);
     }
     if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
     __syncthreads();
@@ -161,12 +166,12 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                 q.hit[mine] = make_float2(w.acc.t, __int_as_float(g >= 0 ? g : WF_MISS));
                 have = false;
             }
-            if (blk < blk_end) {
+            if (blk < n_ray_blocks) {
+                // idle lanes take the rest of the current block in lane order; what does not fit waits
+                // for the next refill, which starts on the wave's next block
                 const uint32_t k = off + lane_rank(idle_mask);
-                const uint32_t next_blk = blk + stride;  // n_in < 2^32, so block numbers stay far below 2^32
-                const unsigned long long idx64 =
-                    k < 64u ? (unsigned long long)blk * 64ull + k : (unsigned long long)next_blk * 64ull + (k - 64u);
-                if (idle && idx64 < (unsigned long long)n_in && (k < 64u || next_blk < blk_end)) {
+                const unsigned long long idx64 = (unsigned long long)blk * 64ull + k;
+                if (idle && k < 64u && idx64 < (unsigned long long)n_in) {
                     mine = (uint32_t)idx64;
                     const float4 a = q.o_dx[mine];
                     const float2 b = q.dyz[mine];
@@ -177,8 +182,8 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                 }
                 off += n_idle;
                 if (off >= 64u) {
-                    off -= 64u;
-                    blk += stride;
+                    off = 0;
+                    next_block();
                 }
             }
             if (__ballot(w.node != BVH_DONE) == 0ull) break;

@@ -30,6 +30,8 @@ constexpr uint32_t WF_MAX_DEPTH = 511;  // 9 bits of the packed sampler word
 struct WfControl {
     uint32_t count[4];        // live paths: count[parity] (two kernels per trip) or count[trip % 3] (one kernel per trip)
     unsigned long long rays;  // closest-hit queries so far
+    uint32_t dyn[2];          // tree kernel: blocks of rays handed out dynamically in the trip of this parity
+    uint32_t pad[2];
 };
 
 // Where a wave takes its next camera samples from.  Sample n of the render (n = s * n_pixels +
