@@ -91,6 +91,7 @@ render_fused(SceneView<R> sv, RenderParams rp) {
     // item bookkeeping reads (one trip in six) are therefore re-read from the kernel argument
     // segment where they are used (scalar loads, no VALU slot) and hidden from loop-invariant
     // hoisting by an empty asm: +2 % on the Cornell box, +8 % on smallpt.
+    static_assert(alignof(SceneView<R>) == 8 && alignof(RenderParams) == 8, "kernel arguments are laid out back to back at 8-byte alignment");
     const char RRT_CONSTANT* kernarg = (const char RRT_CONSTANT*)__builtin_amdgcn_kernarg_segment_ptr();
     const RenderParams RRT_CONSTANT* rpk = (const RenderParams RRT_CONSTANT*)(kernarg + ((sizeof(SceneView<R>) + 7) & ~(size_t)7));
 
