@@ -259,6 +259,13 @@ def main():
         if use_tree:
             out["config"]["node_tests_per_ray"] = tot["node_tests"] / max(tot["rays"], 1)
             out["config"]["prim_tests_per_ray"] = tot["prim_tests"] / max(tot["rays"], 1)
+            # every traversal step fetches one 64-byte record (wide node or leaf primitive) per lane: the tree
+            # kernel is bound by how fast the memory system serves such divergent gathers (L2 + HBM), not by flops
+            steps = tot["node_tests"] + tot["prim_tests"]
+            out["roofline"]["tree_records_per_s"] = steps / kernel_s
+            out["roofline"]["tree_record_traffic_GBps"] = steps * 64 / kernel_s / 1e9
+            out["roofline"]["tree_note"] = ("64 B per traversal step; a fully divergent gather beyond L2 runs at 55-64 G records/s "
+                                            "on this GPU (tools/ubench/gather_rate.hip); PMC: L2 hit rate 0.58, 3.3 TB/s HBM-side")
         if wavefront:
             out["roofline"]["queue_traffic_algorithmic_GBps"] = tot["rays"] * QUEUE_BYTES_PER_RAY / kernel_s / 1e9
         if world == 1 and not args.no_cpu_baseline:
