@@ -219,3 +219,39 @@ def test_empty_scene(gpu, cfg):
     for pipe in (api.PIPELINE_FUSED, api.PIPELINE_WAVEFRONT):
         rgb, st = be.render_accumulate(sc, rc.render_desc(pipeline=pipe))
         assert st["samples"] == 16 * 16 * 4 and st["rays"] == st["samples"] and not rgb.any()
+
+
+def test_million_triangle_scene_tree_equals_scan(gpu, cfg, O):
+    """configs/mesh_1m (two generated 500k-triangle meshes in the Cornell shell, millimetre units): the
+    tree must return what a linear scan over all 998 290 primitives returns, bit for bit, for primary and
+    for scattered rays; the oracle's scan agrees on a smaller set (it tests 1 M triangles per ray)."""
+    import make_c5_assets
+    api, be = gpu
+    make_c5_assets.main()
+    flat = cfg.load_scene(os.path.join(ROOT, "configs", "mesh_1m", "scene.toml"))
+    assert flat.n_prims == 998290
+    sc = api.Scene(flat)
+    rng = np.random.default_rng(9)
+    u, v = rng.random(6000), rng.random(6000)
+    tree = be.trace_primary(sc, u, v, precision=api.PRECISION_F32)  # AUTO -> tree
+    scan = be.trace_primary(sc, u, v, precision=api.PRECISION_F32, accel=api.ACCEL_LINEAR)
+    assert _same(tree, scan)
+    assert (tree[0] >= 4).sum() > 1000  # a good share of the rays meets the two meshes
+    # scattered rays: leave the primary hit points in random directions
+    hit = tree[0] >= 0
+    d0 = np.stack([flat.camera["lower_left_corner"] + uu * flat.camera["horizontal"] + vv * flat.camera["vertical"]
+                   - flat.camera["origin"] for uu, vv in zip(u[hit], v[hit])])
+    d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    o2 = flat.camera["origin"] + d0 * tree[2][hit][:, None]
+    d2 = rng.normal(size=o2.shape)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    for prec in (api.PRECISION_F32, api.PRECISION_F64):
+        a = be.intersect(sc, o2, d2, precision=prec)
+        b = be.intersect(sc, o2, d2, precision=prec, accel=api.ACCEL_LINEAR)
+        assert _same(a, b), prec
+    n = 200
+    ref = O.trace_primary(flat, u[:n], v[:n])
+    got = be.trace_primary(sc, u[:n], v[:n], precision=api.PRECISION_F64)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+    h = ref[0] >= 0
+    assert np.all(np.abs(got[2][h] - ref[2][h]) <= 1e-9 * ref[2][h])
