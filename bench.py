@@ -150,9 +150,9 @@ def main():
     lo, hi = D.shard_range(rc.spp, rank, world)
     pipeline = {"auto": api.PIPELINE_AUTO, "fused": api.PIPELINE_FUSED, "wavefront": api.PIPELINE_WAVEFRONT}[args.pipeline]
     desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline)
-    # what AUTO resolves to (include/rrt.h): the tree for more than 128 primitives, and with it the wavefront pipeline
-    use_tree = flat.n_prims > 128
-    wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and use_tree)
+    # what AUTO resolves to (include/rrt.h): the tree for more than 160 primitives, the wavefront pipeline above 800
+    use_tree = flat.n_prims > 160
+    wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and flat.n_prims > 800)
     post = rc.post_desc()
     acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32, device="cuda")
     img = torch.zeros((rc.height, rc.width, 3), dtype=torch.uint8, device="cuda")
@@ -242,7 +242,7 @@ def main():
             },
             "roofline": {
                 "bound": "valu_fp32",
-                "kernel": ("wf_closest_hit_tree + wf_shade" if use_tree else "wf_closest_hit + wf_shade") if wavefront
+                "kernel": ("wf_closest_hit_tree + wf_shade" if use_tree else "wf_shade<scan>") if wavefront
                 else "render_fused<float>",
                 "achieved": achieved,
                 "peak": PEAK_FP32_VALU_TFLOPS,

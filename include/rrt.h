@@ -62,7 +62,7 @@ typedef enum rrt_sampler_type { RRT_SAMPLER_RANDOM = 0, RRT_SAMPLER_STRATIFIED =
 typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_precision;
 
 /* How closest-hit walks the primitives.  AUTO = wave-uniform linear scan for
- * scenes of up to 128 primitives (where it is the faster of the two), LBVH
+ * scenes of up to 160 primitives (where it is the faster of the two), LBVH
  * (+ linear scan of the unbounded planes) otherwise. */
 typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2 } rrt_accel;
 
@@ -70,8 +70,8 @@ typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBV
  * all of its bounces and refills finished lanes with new camera samples;
  * WAVEFRONT keeps SoA ray and hit queues in HBM and compacts them after every
  * bounce (f32 only, max_depth <= 511).  AUTO: WAVEFRONT when the closest hit
- * goes through the LBVH and the precision is f32, FUSED otherwise.  Both trace
- * the same paths for the same seed. */
+ * goes through the LBVH of a scene with more than 800 primitives and the
+ * precision is f32, FUSED otherwise.  Both trace the same paths for the same seed. */
 typedef enum rrt_pipeline { RRT_PIPELINE_AUTO = 0, RRT_PIPELINE_FUSED = 1, RRT_PIPELINE_WAVEFRONT = 2 } rrt_pipeline;
 
 /* One primitive in the order the reference's linear scan visits it:

@@ -292,10 +292,15 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
-// Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO.  Measured crossover on
-// triangle meshes (tools/gpu_crossover.py): the scan renders 92 primitives at 7.2 Grays/s and 184 at
-// 3.8, the tree + wavefront pipeline stays at 5.7.
-const size_t kAutoBvhThreshold = 128;
+// Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO, and tree scenes with more
+// primitives than kAutoWavefrontThreshold the wavefront pipeline under RRT_PIPELINE_AUTO.  Measured on
+// triangle meshes at 1024x1024 @ 256 spp (tools/gpu_crossover.py), Grays/s:
+//   primitives      92    184    382    758   1484   5854
+//   scan, fused    14.2    7.7    3.9    2.0    1.0    0.3
+//   tree, fused     9.6    8.6    8.2    7.2    6.0    5.4
+//   tree, wavefront 7.6    7.3    7.3    7.1    6.8    6.6     (1 M triangles: 4.8 against 2.6 fused)
+const size_t kAutoBvhThreshold = 160;
+const size_t kAutoWavefrontThreshold = 800;
 // Subtrees of at most this many primitives are folded into one leaf.  A traversal step costs one
 // 64-byte fetch whether it reads a node or a primitive; 2 minimises their sum on triangle meshes.
 const int kBvhLeafMax = 2;
@@ -794,8 +799,8 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     // AUTO: tree traversal wants many waves in flight, which the register-lean closest-hit kernel of
     // the wavefront pipeline has; a scan over a few primitives is fastest with the path in registers
     const bool wavefront = desc->pipeline == RRT_PIPELINE_WAVEFRONT ||
-                           (desc->pipeline == RRT_PIPELINE_AUTO && use_bvh && desc->precision == RRT_PRECISION_F32 &&
-                            desc->max_depth <= rrt::WF_MAX_DEPTH);
+                           (desc->pipeline == RRT_PIPELINE_AUTO && use_bvh && scene->prims.size() > kAutoWavefrontThreshold &&
+                            desc->precision == RRT_PRECISION_F32 && desc->max_depth <= rrt::WF_MAX_DEPTH);
 
     const size_t n_pixels = (size_t)desc->width * desc->height;
     const bool on_device = is_device_pointer(rgb_sum);

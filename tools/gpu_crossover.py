@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.p
 from rustraytracer_amd import api, config
 import test_gpu_lbvh as T
 be = api.Backend(0)
-rc = config.stratified_config(512, 512, 8, 8)
+rc = config.stratified_config(1024, 1024, 16, 16)
 for n in (24, 48, 96, 192, 384, 768, 1536, 6000):
     flat = T.mesh_scene(n)
     sc = api.Scene(flat)
