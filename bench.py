@@ -25,7 +25,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz, packed FP32)
+PEAK_FP64_VALU_TFLOPS = 78.6   # vector FP64: one FMA per lane and clock
 
 # Algorithmic FLOPs, counted from the reference's arithmetic as written
 # (1 per add/sub/mul/div/sqrt, FMA = 2, dead code excluded).
@@ -95,6 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell")
     ap.add_argument("--pipeline", choices=["auto", "fused", "wavefront"], default="auto")
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32",
+                    help="f32 is the product path; f64 runs the same kernels in the reference's arithmetic type")
     ap.add_argument("--spp-side", type=int, default=0, help="strata per axis per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -149,10 +152,11 @@ def main():
     rc = config.stratified_config(width, height, xs, ys)
     lo, hi = D.shard_range(rc.spp, rank, world)
     pipeline = {"auto": api.PIPELINE_AUTO, "fused": api.PIPELINE_FUSED, "wavefront": api.PIPELINE_WAVEFRONT}[args.pipeline]
-    desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline)
+    precision = api.PRECISION_F64 if args.precision == "f64" else api.PRECISION_F32
+    desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline, precision=precision)
     # what AUTO resolves to (include/rrt.h): the tree for more than 160 primitives, the wavefront pipeline above 800
     use_tree = flat.n_prims > 160
-    wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and flat.n_prims > 800)
+    wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and flat.n_prims > 800 and args.precision == "f32")
     post = rc.post_desc()
     acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32, device="cuda")
     img = torch.zeros((rc.height, rc.width, 3), dtype=torch.uint8, device="cuda")
@@ -203,6 +207,7 @@ def main():
         flops = algorithmic_flops(tot, flat)  # rank 0's launches
         kernel_s = tot["kernel_ms"] / 1e3
         achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
+        peak = PEAK_FP32_VALU_TFLOPS if args.precision == "f32" else PEAK_FP64_VALU_TFLOPS
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and args.workload == "cornell" and not wavefront:
@@ -225,7 +230,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.precision,
             "data": "synthetic (scenes of the reference configs; Cornell PLY meshes reconstructed from the canonical "
                     "measurements because the reference ships LFS stubs; the 1M-triangle meshes are generated)",
             "config": {
@@ -241,13 +246,13 @@ def main():
                 "nonfinite_samples": tot["nonfinite"],
             },
             "roofline": {
-                "bound": "valu_fp32",
+                "bound": "valu_fp32" if args.precision == "f32" else "valu_fp64",
                 "kernel": ("wf_closest_hit_tree + wf_shade" if use_tree else "wf_shade<scan>") if wavefront
                 else "render_fused<float>",
                 "achieved": achieved,
-                "peak": PEAK_FP32_VALU_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                "frac": achieved / peak,
                 "traffic": traffic,
                 "algorithmic_flops_per_launch": flops / args.steps,
                 "flops_per_ray_scene": fpr,

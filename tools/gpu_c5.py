@@ -11,7 +11,7 @@ be = api.Backend(0)
 t0 = time.time(); flat = config.load_scene(os.path.join(ROOT, "configs/mesh_1m/scene.toml")); print("load %.2fs prims %d" % (time.time() - t0, flat.n_prims), flush=True)
 t0 = time.time(); sc = api.Scene(flat); print("scene create %.2fs" % (time.time() - t0), flush=True)
 rc = config.stratified_config(W, H, S, S)
-rc.max_depth = 6
+rc.max_depth = int(os.environ.get("C5_MAX_DEPTH", "6"))
 t0 = time.time(); rgb, st = be.render_accumulate(sc, config.stratified_config(64, 64, 2, 2).render_desc(accel=api.ACCEL_LBVH)); print("first call (build) %.2fs" % (time.time() - t0), flush=True)
 for rep in range(2):
     rgb, st = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LBVH))
