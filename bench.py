@@ -43,7 +43,8 @@ WORKLOADS = {
     "cornell": ("configs/cornell_box/scene.toml", 500, 500, 128, 32),
     "smallpt": ("configs/smallpt/scene.toml", 1024, 768, 128, 16),
     "cornell_cube": ("configs/cornell_cube/scene.toml", 1024, 1024, 64, 16),
-    "mesh_1m": ("configs/mesh_1m/scene.toml", 3840, 2160, 32, None),  # the reference scans 1 M triangles per ray
+    # the reference scans 1 M triangles per ray (~10 ms each on a host core): its sample is 64x36 pixels at 4 spp
+    "mesh_1m": ("configs/mesh_1m/scene.toml", 3840, 2160, 32, (64, 36, 2)),
 }
 
 
@@ -83,8 +84,8 @@ def cpu_baseline(flat, name, width, height, side, threads):
         "mrays_per_s": st["rays"] / dt / 1e6,
         "cores": threads,
         "kind": "port",
-        "sample": "%s %dx%d stratified %dx%d = %d spp (%.0f M samples), f64 C restatement of the reference "
-                  "renderer, 16x16 tiles over %d threads, %.1f s"
+        "sample": "%s %dx%d stratified %dx%d = %d spp (%.4g M samples), f64 C restatement of the reference "
+                  "renderer (linear scan of every primitive per ray), 16x16 tiles over %d threads, %.1f s"
                   % (name, width, height, side, side, side * side, st["samples"] / 1e6, threads, dt),
     }
 
@@ -274,11 +275,9 @@ def main():
         if wavefront:
             out["roofline"]["queue_traffic_algorithmic_GBps"] = tot["rays"] * QUEUE_BYTES_PER_RAY / kernel_s / 1e9
         if world == 1 and not args.no_cpu_baseline:
-            if cpu_side is None:
-                out["cpu_baseline"] = None  # a linear scan of 1 M triangles per ray: not timed
-            else:
-                threads = min(os.cpu_count() or 1, 16)
-                out["cpu_baseline"] = cpu_baseline(flat, args.workload, width, height, cpu_side, threads)
+            threads = min(os.cpu_count() or 1, 16)
+            cw, ch, cs = cpu_side if isinstance(cpu_side, tuple) else (width, height, cpu_side)
+            out["cpu_baseline"] = cpu_baseline(flat, args.workload, cw, ch, cs, threads)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
