@@ -1,0 +1,181 @@
+"""The reference's shape and camera tests (src/shapes/*.rs, src/camera.rs #[cfg(test)]) restated against the
+HIP closest-hit kernels, through the C ABI: one-primitive scenes, the reference's random constructions
+(seeded), both precisions, linear scan and tree.
+
+Scene::intersect starts its range at t = 0.001 (src/scene.rs:36) where the reference's shape tests start
+at 0, so rays whose hit lies closer than 0.01 are left out; in f32 so are rays that graze a sphere or
+pass within 1e-3 of an edge (the verdict there is a matter of rounding), and tolerances are those of
+f32 arithmetic on coordinates of size 10."""
+import numpy as np
+import pytest
+
+import scenes_util as S
+from rustraytracer_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+MATS = [(_abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)]
+RAYS = 64
+
+
+def _unit(v):
+    return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def _rays_through(rng, anchor, reach, n=RAYS):
+    """n rays through two random points around `anchor` each (the reference's construction)."""
+    p1 = anchor + _unit(rng.uniform(-1, 1, (n, 3))) * rng.uniform(0, reach, (n, 1))
+    p2 = anchor + _unit(rng.uniform(-1, 1, (n, 3))) * rng.uniform(0, reach, (n, 1))
+    return p1, _unit(p2 - p1)
+
+
+def _modes(api):
+    return [(prec, accel) for prec in (api.PRECISION_F64, api.PRECISION_F32) for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH)]
+
+
+def test_sphere_geometric_equals_analytic(gpu):  # src/shapes/sphere.rs:129-179
+    api, be = gpu
+    rng = np.random.default_rng(10)
+    hits = 0
+    for _ in range(40):
+        c, r = rng.uniform(-10, 10, 3), rng.uniform(0.1, 10)
+        o, d = _rays_through(rng, c, 2 * r)
+        sc = api.Scene(S.make_scene([(0, 0, 0, [*c, r])], MATS))
+        # analytic: |o + t d - c|^2 = r^2, nearest root beyond the range start
+        oc = o - c
+        b, cc = np.einsum("ij,ij->i", oc, d), np.einsum("ij,ij->i", oc, oc) - r * r
+        disc = b * b - cc
+        root = np.sqrt(np.maximum(disc, 0))
+        t0, t1 = -b - root, -b + root
+        want = np.where(t0 > 0.001, t0, t1)
+        want_hit = (disc >= 0) & (want > 0.001)
+        for prec, accel in _modes(api):
+            oid, pid, t = be.intersect(sc, o, d, precision=prec, accel=accel)
+            f32 = prec == api.PRECISION_F32
+            clear = (np.abs(disc) > (1e-3 if f32 else 1e-9) * r * r) & (np.abs(want - 0.001) > 0.009)
+            assert np.array_equal((oid >= 0)[clear], want_hit[clear])
+            both = clear & want_hit
+            tol = 2e-4 * (np.abs(b) + root + r) if f32 else 1e-6  # the reference's gate is 1e-6
+            assert np.all(np.abs(t[both] - want[both]) <= (tol[both] if f32 else tol))
+            hits += int(both.sum())
+    assert hits > 2000
+
+
+def test_plane_hit_lies_on_plane(gpu):  # src/shapes/plane.rs:71-123
+    api, be = gpu
+    rng = np.random.default_rng(11)
+    hits = 0
+    for _ in range(40):
+        point, normal = rng.uniform(-10, 10, 3), _unit(rng.uniform(-1, 1, 3))
+        o, d = _rays_through(rng, point, 10)
+        sc = api.Scene(S.make_scene([(1, 0, 0, [*point, *normal])], MATS))
+        for prec in (api.PRECISION_F64, api.PRECISION_F32):  # an unbounded plane never enters the tree
+            oid, pid, t = be.intersect(sc, o, d, precision=prec)
+            h = oid >= 0
+            p = o[h] + t[h, None] * d[h]
+            tol = 1e-6 if prec == api.PRECISION_F64 else 2e-5 * (10 + t[h])
+            assert np.all(np.abs((p - point) @ normal) <= tol)
+            # every ray that is not parallel and points at the plane hits it
+            nd = d @ normal
+            want = ((point - o) @ normal) / nd
+            clear = (np.abs(nd) > 1e-4) & (np.abs(want - 0.001) > 0.009)
+            assert np.array_equal(h[clear], (want > 0.001)[clear])
+            hits += int(h.sum())
+    assert hits > 500
+
+
+def test_triangle_hit_on_plane_and_barycentrics(gpu):  # src/shapes/triangle.rs:121-185
+    api, be = gpu
+    rng = np.random.default_rng(12)
+    hits = 0
+    for _ in range(60):
+        v = rng.uniform(-10, 10, (3, 3))
+        o, d = _rays_through(rng, v[0], 10)
+        sc = api.Scene(S.make_scene([(2, 0, 0, v)], MATS))
+        normal = _unit(np.cross(v[1] - v[0], v[2] - v[0]))
+        denom = np.linalg.norm(np.cross(v[1] - v[0], v[2] - v[0]))
+        for prec, accel in _modes(api):
+            oid, pid, t = be.intersect(sc, o, d, precision=prec, accel=accel)
+            h = oid >= 0
+            f32 = prec == api.PRECISION_F32
+            p = o[h] + t[h, None] * d[h]
+            assert np.all(np.abs((p - v[0]) @ normal) <= (1e-3 if not f32 else 1e-3 + 2e-5 * t[h]))  # the reference's gate
+            bu = np.linalg.norm(np.cross(v[2] - v[0], p - v[0]), axis=1) / denom
+            bv = np.linalg.norm(np.cross(v[0] - v[1], p - v[1]), axis=1) / denom
+            slack = 1e-3 if f32 else 1e-9
+            assert np.all(bu <= 1 + slack) and np.all(bv <= 1 + slack) and np.all(bu + bv <= 1 + slack)
+            hits += int(h.sum())
+    assert hits > 100
+
+
+def test_quad_equals_two_triangles(gpu, cfg):  # src/shapes/quadrilateral.rs:268-326
+    api, be = gpu
+    rng = np.random.default_rng(15)
+    checked = 0
+    done = 0
+    while done < 40:
+        v = np.array([[rng.uniform(-10, 0), rng.uniform(0, 10), 0], [rng.uniform(-10, 0), rng.uniform(-10, 0), 0],
+                      [rng.uniform(0, 10), rng.uniform(-10, 0), 0], [rng.uniform(0, 10), rng.uniform(0, 10), 0]])
+        if not cfg.is_quadrilateral_convex(*v):
+            continue
+        done += 1
+        p1 = np.stack([rng.uniform(-10, 10, RAYS), rng.uniform(-10, 10, RAYS), rng.uniform(-10, 0, RAYS)], axis=1)
+        p2 = np.stack([rng.uniform(-10, 10, RAYS), rng.uniform(-10, 10, RAYS), rng.uniform(0, 10, RAYS)], axis=1)
+        o, d = p1, _unit(p2 - p1)
+        quad = api.Scene(S.make_scene([(3, 0, 0, v)], MATS))
+        tris = api.Scene(S.make_scene([(2, 0, 0, v[[0, 1, 2]]), (2, 0, 1, v[[0, 2, 3]])], MATS))
+        # distance of the hit point in the quad's plane from its outline and its diagonal (for the f32 filter)
+        tp = -o[:, 2] / d[:, 2]
+        P = o + tp[:, None] * d
+        edge_dist = np.full(RAYS, np.inf)
+        for a, b in ((0, 1), (1, 2), (2, 3), (3, 0), (0, 2)):
+            e = _unit(v[b] - v[a])
+            w = P - v[a]
+            edge_dist = np.minimum(edge_dist, np.abs(w[:, 0] * e[1] - w[:, 1] * e[0]))
+        for prec, accel in _modes(api):
+            hq = be.intersect(quad, o, d, precision=prec, accel=accel)
+            ht = be.intersect(tris, o, d, precision=prec, accel=accel)
+            f32 = prec == api.PRECISION_F32
+            clear = (edge_dist > 1e-3) if f32 else (edge_dist > 1e-9)
+            assert np.array_equal((hq[0] >= 0)[clear], (ht[0] >= 0)[clear])
+            both = clear & (hq[0] >= 0)
+            pq = o[both] + hq[2][both, None] * d[both]
+            pt = o[both] + ht[2][both, None] * d[both]
+            assert np.all(np.linalg.norm(pq - pt, axis=1) < (1e-6 if not f32 else 2e-4))  # the reference's gate: 1e-6
+            checked += int(both.sum())
+    assert checked > 250 * len(_modes(api))
+
+
+def test_quad_normal_and_triangle_range_known_answers(gpu):
+    """The alpha + beta > 1 corner of a quad (src/shapes/quadrilateral.rs:164-216), and the open upper end of
+    a triangle's range (src/shapes/triangle.rs:56): of two coincident triangles the scan keeps the first."""
+    api, be = gpu
+    v = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], dtype=float)
+    sc = api.Scene(S.make_scene([(3, 0, 0, v)], MATS))
+    for prec, accel in _modes(api):
+        oid, pid, t = be.intersect(sc, np.array([[0.9, 0.9, 1.0]]), np.array([[0, 0, -1.0]]), precision=prec, accel=accel)
+        assert oid[0] == 0 and abs(t[0] - 1) < 1e-6
+    # two coincident triangles: the later one must not replace the earlier one at equal t (triangle.rs:56)
+    tri = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+    sc = api.Scene(S.make_scene([(2, 0, 0, tri), (2, 1, 0, tri)], MATS * 2))
+    for prec, accel in _modes(api):
+        oid, pid, t = be.intersect(sc, np.array([[0.25, 0.25, 1.0]]), np.array([[0, 0, -1.0]]), precision=prec, accel=accel)
+        assert oid[0] == 0 and t[0] == 1.0
+
+
+def test_perspective_camera_known_answer(gpu):  # src/camera.rs:82-102
+    """Camera at the origin looking down -z, vfov 90, aspect 2: (u, v) = (0.5, 0.5) is the ray (0, 0, -1) and
+    the corners of the image plane are (+-2, +-1, -1) -- probed through a plane at z = -5."""
+    api, be = gpu
+    flat = S.make_scene([(1, 0, 0, [0, 0, -5, 0, 0, 1])], MATS, look_from=(0, 0, 0), look_at=(0, 0, -1), vup=(0, 1, 0),
+                        vfov=90.0, aspect=2.0)
+    sc = api.Scene(flat)
+    u = np.array([0.5, 0.0, 1.0, 0.0, 1.0])
+    v = np.array([0.5, 0.0, 0.0, 1.0, 1.0])
+    for prec in (api.PRECISION_F64, api.PRECISION_F32):
+        oid, pid, t = be.trace_primary(sc, u, v, precision=prec)
+        assert np.all(oid == 0)
+        tol = 1e-12 if prec == api.PRECISION_F64 else 1e-5
+        assert abs(t[0] - 5.0) <= tol
+        corner = 5.0 * np.sqrt(2 * 2 + 1 * 1 + 1)  # |(+-2, +-1, -1)| x 5
+        assert np.all(np.abs(t[1:] - corner) <= tol * corner)
