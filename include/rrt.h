@@ -215,6 +215,19 @@ int rrt_render(rrt_backend* backend, const rrt_scene* scene, const rrt_render_de
  * stratum of every dimension is visited exactly once per pixel. */
 int rrt_sampler_values(rrt_backend* backend, const rrt_render_desc* desc, uint32_t pixel, float* out_host);
 
+/* Material::scatter (src/material.rs:38-284) and the throughput factor cos * bxdf / pdf of
+ * generate_camera_vertices (src/tracers/utils.rs:66-87) for n independent samples of ONE material,
+ * with the random numbers supplied by the caller: sample i has incoming direction d_in[3i..], surface
+ * normal normal[3i..] (both unit vectors) and u[3i..] = (get_1d, get_2d.x, get_2d.y), the draws a
+ * material may ask for (IdealDielectric uses the 1D draw, the two lobe samplers the 2D draw).
+ * ok[i] = 1 when the material scatters (0 for the reference's None, and for a throughput of exactly
+ * zero); then d_out[3i..] is the new direction and weight[3i..] the factor applied to the path
+ * throughput.  All arrays are host memory.  A probe for tests, like rrt_sampler_values: the kernels
+ * behind it are the device functions the renderers call per bounce. */
+int rrt_material_probe(rrt_backend* backend, const rrt_material* material, uint32_t precision, size_t n,
+                       const double* d_in, const double* normal, const double* u, double* d_out, double* weight,
+                       int32_t* ok);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,8 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(PostDesc), C.c_uint32, C.c_uint32, C.c_void_p],
     ),
     "rrt_sampler_values": (C.c_int, [C.c_void_p, C.POINTER(RenderDesc), C.c_uint32, C.c_void_p]),
+    "rrt_material_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "rrt_render": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.POINTER(RenderDesc), C.POINTER(PostDesc), C.c_void_p, C.POINTER(Stats)],

@@ -127,6 +127,20 @@ class Backend:
         _abi.check(self._lib, self._lib.rrt_sampler_values(self.handle, C.byref(render_desc), int(pixel), _ptr(out)))
         return out
 
+    def material_probe(self, material, d_in, normal, u, precision=PRECISION_F32):
+        """Material::scatter + throughput factor for n samples of one material (a MATERIAL_DTYPE record):
+        d_in, normal [n, 3]; u [n, 3] = (get_1d, get_2d.x, get_2d.y) -> (d_out [n, 3], weight [n, 3], ok [n])."""
+        mat = np.ascontiguousarray(np.asarray(material, dtype=_abi.MATERIAL_DTYPE).reshape(1))
+        d_in, normal, u = (np.ascontiguousarray(a, dtype=np.float64).reshape(-1, 3) for a in (d_in, normal, u))
+        n = d_in.shape[0]
+        if normal.shape[0] != n or u.shape[0] != n:
+            raise ValueError("d_in, normal and u must have the same length")
+        d_out, weight = np.zeros((n, 3)), np.zeros((n, 3))
+        ok = np.zeros(n, dtype=np.int32)
+        _abi.check(self._lib, self._lib.rrt_material_probe(self.handle, _ptr(mat), int(precision), n, _ptr(d_in), _ptr(normal),
+                                                           _ptr(u), _ptr(d_out), _ptr(weight), _ptr(ok)))
+        return d_out, weight, ok.astype(bool)
+
     def postprocess(self, rgb_sum, spp_divisor, post_desc, out=None):
         """mean -> tone map -> gamma -> white balance -> u8.  Returns uint8 [H, W, 3]."""
         if isinstance(rgb_sum, np.ndarray):

@@ -878,6 +878,38 @@ int rrt_sampler_values(rrt_backend* be, const rrt_render_desc* desc, uint32_t pi
     return RRT_OK;
 }
 
+int rrt_material_probe(rrt_backend* be, const rrt_material* material, uint32_t precision, size_t n, const double* d_in,
+                       const double* normal, const double* u, double* d_out, double* weight, int32_t* ok) {
+    int rc = check_backend(be);
+    if (rc != RRT_OK) return rc;
+    if (!material) return fail(RRT_ERR_INVALID, "material is NULL");
+    if (material->type > RRT_MAT_DIELECTRIC) return fail(RRT_ERR_INVALID, "unknown material type %u", material->type);
+    if (precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", precision);
+    if (n == 0) return RRT_OK;
+    if (!d_in || !normal || !u || !d_out || !weight || !ok) return fail(RRT_ERR_INVALID, "NULL argument");
+    rrt::MatRec<double> m;
+    prepare_material(*material, m);
+    // one staging buffer: three inputs, two outputs of 3 doubles per sample, then the flags
+    DevBuf buf;
+    const size_t vec = n * 3 * sizeof(double);
+    HIP_TRY(buf.alloc(5 * vec + n * sizeof(int32_t)));
+    double* d = (double*)buf.p;
+    double *dd_in = d, *dd_n = d + 3 * n, *dd_u = d + 6 * n, *dd_out = d + 9 * n, *dd_w = d + 12 * n;
+    int32_t* d_ok = (int32_t*)(d + 15 * n);
+    HIP_TRY(hipMemcpyAsync(dd_in, d_in, vec, hipMemcpyHostToDevice, be->stream));
+    HIP_TRY(hipMemcpyAsync(dd_n, normal, vec, hipMemcpyHostToDevice, be->stream));
+    HIP_TRY(hipMemcpyAsync(dd_u, u, vec, hipMemcpyHostToDevice, be->stream));
+    if (precision == RRT_PRECISION_F64)
+        HIP_TRY(rrt::launch_material_probe(m, n, dd_in, dd_n, dd_u, dd_out, dd_w, d_ok, be->stream));
+    else
+        HIP_TRY(rrt::launch_material_probe(narrow<float>(m), n, dd_in, dd_n, dd_u, dd_out, dd_w, d_ok, be->stream));
+    HIP_TRY(hipMemcpyAsync(d_out, dd_out, vec, hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipMemcpyAsync(weight, dd_w, vec, hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipMemcpyAsync(ok, d_ok, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipStreamSynchronize(be->stream));
+    return RRT_OK;
+}
+
 int rrt_postprocess(rrt_backend* be, const float* rgb_sum, uint64_t spp_divisor, const rrt_post_desc* post,
                     uint32_t width, uint32_t height, uint8_t* rgb8) {
     int rc = check_backend(be);

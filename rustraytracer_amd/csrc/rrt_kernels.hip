@@ -290,6 +290,37 @@ __global__ void __launch_bounds__(256) sampler_values_kernel(RenderParams rp, ui
     get_2d<float>(s, rp, o[6], o[7]);
 }
 
+// ------------------------------------------------------------------ material probe
+// Material::scatter + the throughput factor for n independent (incoming direction, normal) pairs of
+// one material, with the random numbers supplied by the caller: the code the renderers run per
+// bounce, made observable one sample at a time.
+template <typename R>
+__global__ void __launch_bounds__(256)
+material_probe_kernel(MatRec<R> m, size_t n, const double* __restrict__ d_in, const double* __restrict__ normal,
+                      const double* __restrict__ u, double* __restrict__ d_out, double* __restrict__ weight,
+                      int32_t* __restrict__ ok) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Path<R> p;
+    p.o = mk<R>(0, 0, 0);
+    p.d = mk<R>((R)d_in[3 * i], (R)d_in[3 * i + 1], (R)d_in[3 * i + 2]);
+    p.beta = mk<R>(1, 1, 1);
+    p.depth = 0;
+    p.smp = Sampler{0, 0, 0, 0, 4};
+    const V3<R> nn = mk<R>((R)normal[3 * i], (R)normal[3 * i + 1], (R)normal[3 * i + 2]);
+    const R r1 = (R)u[3 * i];
+    bool good = false;
+    if (m.type != MAT_EMISSIVE)  // an emitter's scatter returns None (src/material.rs:44-46)
+        good = scatter_with<R>(p, m.type, nn, m, (R)u[3 * i + 1], (R)u[3 * i + 2], [&]() { return r1; });
+    ok[i] = good ? 1 : 0;
+    d_out[3 * i] = (double)p.d.x;
+    d_out[3 * i + 1] = (double)p.d.y;
+    d_out[3 * i + 2] = (double)p.d.z;
+    weight[3 * i] = (double)p.beta.x;
+    weight[3 * i + 1] = (double)p.beta.y;
+    weight[3 * i + 2] = (double)p.beta.z;
+}
+
 // ------------------------------------------------------------------ post-process
 // src/renderer.rs:39-71,128-136 in f64 (the reference's arithmetic type); one
 // thread per colour component.
@@ -357,6 +388,23 @@ hipError_t launch_render_fused(const SceneView<float>& sv, bool bvh, const Rende
 }
 hipError_t launch_render_fused(const SceneView<double>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
     return launch_render_fused_t<double>(sv, bvh, rp, n_blocks, s);
+}
+
+template <typename R>
+static hipError_t launch_material_probe_t(const MatRec<R>& m, size_t n, const double* d_in, const double* normal, const double* u,
+                                          double* d_out, double* weight, int32_t* ok, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(material_probe_kernel<R>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, m, n, d_in, normal, u,
+                       d_out, weight, ok);
+    return hipGetLastError();
+}
+hipError_t launch_material_probe(const MatRec<float>& m, size_t n, const double* d_in, const double* normal, const double* u,
+                                 double* d_out, double* weight, int32_t* ok, hipStream_t stream) {
+    return launch_material_probe_t<float>(m, n, d_in, normal, u, d_out, weight, ok, stream);
+}
+hipError_t launch_material_probe(const MatRec<double>& m, size_t n, const double* d_in, const double* normal, const double* u,
+                                 double* d_out, double* weight, int32_t* ok, hipStream_t stream) {
+    return launch_material_probe_t<double>(m, n, d_in, normal, u, d_out, weight, ok, stream);
 }
 
 hipError_t launch_sampler_values(const RenderParams& rp, uint32_t pixel, float* out, hipStream_t stream) {

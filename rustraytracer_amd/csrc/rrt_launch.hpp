@@ -25,6 +25,12 @@ hipError_t launch_render_fused(const SceneView<double>& sv, bool bvh, const Rend
 
 hipError_t launch_sampler_values(const RenderParams& rp, uint32_t pixel, float* out, hipStream_t stream);
 
+// all pointers are device memory: d_in, normal, u, d_out, weight hold 3 doubles per sample
+hipError_t launch_material_probe(const MatRec<float>& m, size_t n, const double* d_in, const double* normal, const double* u,
+                                 double* d_out, double* weight, int32_t* ok, hipStream_t stream);
+hipError_t launch_material_probe(const MatRec<double>& m, size_t n, const double* d_in, const double* normal, const double* u,
+                                 double* d_out, double* weight, int32_t* ok, hipStream_t stream);
+
 hipError_t launch_postprocess(const float* sum, double inv_spp, const PostParams& pp, size_t n_components,
                               uint8_t* out, hipStream_t stream);
 

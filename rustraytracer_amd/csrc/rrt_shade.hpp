@@ -115,8 +115,10 @@ RRT_DEV int process_hit(const RenderParams& rp, Path<R>& p, const ShadeRec<R>& s
 //   IdealDielectric reflect: c (F/c) / F = 1; refract: c ((1-F)/(c eta^2)) / (1-F) = 1/eta^2
 //                   (0 if |d.n| < 1e-6)
 // A path whose throughput became exactly zero is dropped: it can only add zero.
-template <typename R>
-RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u, R v) {
+// draw_1d() supplies the dielectric's reflect-or-refract draw (the path's sampler in the renderers,
+// a given number in the material probe).
+template <typename R, typename Draw1D>
+RRT_DEV bool scatter_with(Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u, R v, Draw1D draw_1d) {
     V3<R> dir;
     if (mode == MAT_LAMBERTIAN) {  // src/material.rs:67-91
         R cos_t = Num<R>::sqrt(R(1) - u);  // theta = acos(sqrt(1 - u))
@@ -152,7 +154,7 @@ RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, cons
         R eta_t = inside ? R(1) : m.param;
         R eta = eta_i * Num<R>::rcp(eta_t);
         R cos_theta = -dot(p.d, on);
-        R r = get_1d<R>(p.smp, rp, true);
+        R r = draw_1d();
         R F = fresnel<R>(cos_theta, eta_i, eta_t);
         R pdf, w;
         if (r < F) {
@@ -175,6 +177,11 @@ RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, cons
     p.d = dir;
     p.depth += 1;
     return !(p.beta.x == R(0) && p.beta.y == R(0) && p.beta.z == R(0));
+}
+
+template <typename R>
+RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u, R v) {
+    return scatter_with<R>(p, mode, n, m, u, v, [&]() { return get_1d<R>(p.smp, rp, true); });
 }
 
 }  // namespace rrt
