@@ -365,7 +365,73 @@ typedef struct {
     size_t current_dimension;
     rng_t rng;
     uint64_t draws;
+    /* device_numbers != 0: the numbers come from the HIP backend's counter-based generator (below) */
+    int device_numbers;
+    uint32_t seed_lo, seed_hi, pixel, pixkey, key, ctr, perm_mask;
 } sampler_t;
+
+/* ---- the HIP backend's number generator, restated (rustraytracer_amd/csrc/rrt_device.hpp) ----
+ * NOT part of the reference: rand::thread_rng is seeded by the OS, so the reference never renders
+ * the same image twice, and any source of uniform numbers behind the Sampler trait
+ * (src/sampler.rs:6-23) is a valid one.  This source returns, call for call, what the device's
+ * sampler returns for (seed, pixel, sample): a hash for every draw, and Kensler's hash permutation
+ * ("Correlated Multi-Jittered Sampling", Pixar TM 13-01) in place of the shuffled stratum tables.
+ * With it the oracle traces the very paths the f64 device kernels trace, and the two renders can
+ * be compared pixel by pixel instead of statistically. */
+static uint32_t dev_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+static uint32_t dev_permute(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
+    do {
+        i ^= p; i *= 0xe170893dU; i ^= p >> 16; i ^= (i & w) >> 4; i ^= p >> 8; i *= 0x0929eb3fU;
+        i ^= p >> 23; i ^= (i & w) >> 1; i *= 1U | p >> 27; i *= 0x6935fa69U; i ^= (i & w) >> 11;
+        i *= 0x74dcb303U; i ^= (i & w) >> 2; i *= 0x9e501cc3U; i ^= (i & w) >> 2; i *= 0xc860a3dfU;
+        i &= w; i ^= i >> 5;
+    } while (i >= l);
+    uint32_t r = i + p;
+    return (l & (l - 1)) == 0 ? (r & w) : (r % l);
+}
+static double dev_uniform(sampler_t* s) {
+    uint32_t bits = dev_mix32(s->key + (s->ctr++) * 0x9E3779B9U);
+    return (double)bits * 2.3283064365386962890625e-10; /* 2^-32 */
+}
+static void dev_start_sample(sampler_t* s) {
+    s->key = dev_mix32(s->pixkey + (uint32_t)s->current_sample * 0x9E3779B9U);
+    s->ctr = 0;
+    s->current_dimension = s->type == RRT_SAMPLER_STRATIFIED ? 0 : SAMPLER_DIMS;
+}
+static void dev_start_pixel(sampler_t* s) {
+    s->pixkey = dev_mix32(s->seed_lo ^ dev_mix32(s->pixel * 0x9E3779B1U + (dev_mix32(s->seed_hi) | 1U)));
+    uint32_t w = (uint32_t)s->spp - 1; /* next power of two - 1 */
+    w |= w >> 1; w |= w >> 2; w |= w >> 4; w |= w >> 8; w |= w >> 16;
+    s->perm_mask = w;
+    s->current_sample = 0;
+    dev_start_sample(s);
+}
+static double dev_get_1d(sampler_t* s) {
+    if (s->current_dimension < SAMPLER_DIMS) {
+        uint32_t d = (uint32_t)s->current_dimension++;
+        uint32_t k = dev_mix32(s->pixkey ^ ((2u * d + 1u) * 0x9E3779B9U));
+        uint32_t stratum = dev_permute((uint32_t)s->current_sample, (uint32_t)s->spp, s->perm_mask, k);
+        return ((double)stratum + dev_uniform(s)) / (double)s->spp;
+    }
+    return dev_uniform(s);
+}
+static void dev_get_2d(sampler_t* s, double* a, double* b) {
+    double j0 = dev_uniform(s), j1 = dev_uniform(s);
+    if (s->current_dimension < SAMPLER_DIMS) {
+        uint32_t d = (uint32_t)s->current_dimension++;
+        uint32_t k = dev_mix32(s->pixkey ^ ((2u * d + 2u) * 0x9E3779B9U));
+        uint32_t cell = dev_permute((uint32_t)s->current_sample, (uint32_t)s->spp, s->perm_mask, k);
+        uint32_t yc = cell / (uint32_t)s->x_strata, xc = cell - yc * (uint32_t)s->x_strata;
+        *a = ((double)xc + j0) / (double)s->x_strata;
+        *b = ((double)yc + j1) / (double)s->y_strata;
+        return;
+    }
+    *a = j0;
+    *b = j1;
+}
 
 static int sampler_init(sampler_t* s, const rrt_render_desc* rd, uint64_t seed, uint64_t stream) {
     memset(s, 0, sizeof(*s));
@@ -419,6 +485,7 @@ static void generate_samples(sampler_t* s) {
 
 /* start_pixel  src/sampler.rs:36-38 (Random), 129-133 (Stratified) */
 static void sampler_start_pixel(sampler_t* s) {
+    if (s->device_numbers) { dev_start_pixel(s); return; }
     s->current_sample = 0;
     if (s->type == RRT_SAMPLER_STRATIFIED) {
         s->current_dimension = 0;
@@ -428,6 +495,7 @@ static void sampler_start_pixel(sampler_t* s) {
 /* get_1d  src/sampler.rs:40-42, 135-142 */
 static double sampler_get_1d(sampler_t* s) {
     s->draws++;
+    if (s->device_numbers) return dev_get_1d(s);
     if (s->type == RRT_SAMPLER_RANDOM || s->current_dimension >= SAMPLER_DIMS)
         return rng_f64(&s->rng);
     double v = s->s1d[s->current_dimension][s->current_sample];
@@ -437,6 +505,7 @@ static double sampler_get_1d(sampler_t* s) {
 /* get_2d  src/sampler.rs:44-46, 144-151 */
 static void sampler_get_2d(sampler_t* s, double* a, double* b) {
     s->draws++;
+    if (s->device_numbers) { dev_get_2d(s, a, b); return; }
     if (s->type == RRT_SAMPLER_RANDOM || s->current_dimension >= SAMPLER_DIMS) {
         *a = rng_f64(&s->rng);
         *b = rng_f64(&s->rng);
@@ -451,12 +520,17 @@ static void sampler_get_2d(sampler_t* s, double* a, double* b) {
  * 153-161 (Stratified: exactly spp) */
 static int sampler_start_next_sample(sampler_t* s) {
     if (s->type == RRT_SAMPLER_RANDOM) {
-        if (s->current_sample < s->spp) { s->current_sample += 1; return 1; }
+        if (s->current_sample < s->spp) {
+            s->current_sample += 1;
+            if (s->device_numbers) dev_start_sample(s);
+            return 1;
+        }
         return 0;
     }
     if (s->current_sample < s->spp - 1) {
         s->current_sample += 1;
         s->current_dimension = 0;
+        if (s->device_numbers) dev_start_sample(s);
         return 1;
     }
     return 0;
@@ -636,6 +710,7 @@ typedef struct {
     pthread_mutex_t lock;
     uint64_t samples, rays, rays_live, bounces[5], nonfinite;
     int failed;
+    int device_numbers;
 } render_job;
 
 /* One 16x16 tile: src/renderer.rs:104-140 */
@@ -653,8 +728,12 @@ static void render_tile(render_job* job, size_t tile_index, trace_counters* cnt,
         sampler_free(&sampler);
         return;
     }
+    sampler.device_numbers = job->device_numbers;
+    sampler.seed_lo = (uint32_t)rd->seed;
+    sampler.seed_hi = (uint32_t)(rd->seed >> 32);
     for (size_t y = y_start; y < y_end; ++y) {
         for (size_t x = x_start; x < x_end; ++x) {
+            sampler.pixel = (uint32_t)(y * rd->width + x);
             sampler_start_pixel(&sampler);
             v3 color = V(0, 0, 0);
             for (;;) {
@@ -699,8 +778,20 @@ static void* render_worker(void* arg) {
 /* The tile loop of render  src/renderer.rs:92-141; rgb_sum receives the
  * per-pixel SUM over samples (the division by spp is in oracle_postprocess).
  * Threads pull tiles from a shared counter, as rayon's par_iter does. */
+static int render_accumulate_impl(const rrt_scene_desc* scene, const rrt_render_desc* rd,
+                                  double* rgb_sum, rrt_stats* stats, int n_threads, int device_numbers);
 int oracle_render_accumulate(const rrt_scene_desc* scene, const rrt_render_desc* rd,
                              double* rgb_sum, rrt_stats* stats, int n_threads) {
+    return render_accumulate_impl(scene, rd, rgb_sum, stats, n_threads, 0);
+}
+/* The same render with the numbers of the HIP backend's generator (see dev_mix32 above): the image the
+ * f64 device kernels must reproduce pixel by pixel for the same seed. */
+int oracle_render_accumulate_device_numbers(const rrt_scene_desc* scene, const rrt_render_desc* rd,
+                                            double* rgb_sum, rrt_stats* stats, int n_threads) {
+    return render_accumulate_impl(scene, rd, rgb_sum, stats, n_threads, 1);
+}
+static int render_accumulate_impl(const rrt_scene_desc* scene, const rrt_render_desc* rd,
+                                  double* rgb_sum, rrt_stats* stats, int n_threads, int device_numbers) {
     if (!scene || !rd || !rgb_sum || rd->width == 0 || rd->height == 0 || rd->spp == 0) return -1;
     if (rd->sampler_type == RRT_SAMPLER_STRATIFIED &&
         (uint64_t)rd->x_strata * rd->y_strata != rd->spp)
@@ -710,6 +801,7 @@ int oracle_render_accumulate(const rrt_scene_desc* scene, const rrt_render_desc*
     job.scene = scene;
     job.rd = rd;
     job.rgb_sum = rgb_sum;
+    job.device_numbers = device_numbers;
     job.tiles_x = (rd->width + 15) / 16;
     job.tile_count = job.tiles_x * ((rd->height + 15) / 16);
     pthread_mutex_init(&job.lock, NULL);

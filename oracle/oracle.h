@@ -20,6 +20,9 @@ int oracle_trace_primary(const rrt_scene_desc* scene, size_t n, const double* u,
                          int32_t* object_id, int32_t* prim_id, double* t);
 int oracle_render_accumulate(const rrt_scene_desc* scene, const rrt_render_desc* rd,
                              double* rgb_sum, rrt_stats* stats, int n_threads);
+/* the same render drawing its random numbers from the restated generator of the HIP backend */
+int oracle_render_accumulate_device_numbers(const rrt_scene_desc* scene, const rrt_render_desc* rd,
+                             double* rgb_sum, rrt_stats* stats, int n_threads);
 int oracle_postprocess(const double* rgb_sum, uint64_t spp_divisor, const rrt_post_desc* post,
                        uint32_t width, uint32_t height, uint8_t* rgb8, double* rgb_linear);
 

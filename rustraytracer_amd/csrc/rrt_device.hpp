@@ -188,18 +188,23 @@ RRT_DEV void sampler_start(Sampler& s, const RenderParams& rp, uint32_t pixkey, 
 
 // get_1d.  `needed` = false when the caller will not look at the value (the
 // Russian-roulette draw against probability 1, src/tracers/utils.rs:56-63):
-// the dimension is still consumed, as in the reference.
+// the dimension and the draw are still consumed, as in the reference, so the
+// numbers a sample sees depend on the sequence of calls only -- a CPU sampler
+// that restates this generator then reproduces the device's paths.
 template <typename R>
 RRT_DEV R get_1d(Sampler& s, const RenderParams& rp, bool needed) {
+    if (!needed) {
+        s.dim += s.dim < 4u ? 1u : 0u;
+        s.ctr += 1u;
+        return R(0);
+    }
     if (s.dim < 4u) {
         uint32_t d = s.dim++;
-        if (!needed) return R(0);
         uint32_t k = mix32(s.pixkey ^ ((2u * d + 1u) * 0x9E3779B9U));
         uint32_t stratum = permute(s.sample, rp.spp, rp.perm_mask, k);
         R j = Num<R>::uniform(next_bits(s));
         return stratum_value(stratum, j, rp.spp, rp.inv_spp);  // (i + xi) / spp, src/sampler.rs:108
     }
-    if (!needed) return R(0);
     return Num<R>::uniform(next_bits(s));
 }
 

@@ -37,8 +37,18 @@ RRT_DEV R fresnel(R cos_i, R eta_i, R eta_t) {
 // the sampled direction does not depend on which basis is taken.  This one is the branch-free
 // construction of Duff et al. ("Building an Orthonormal Basis, Revisited", JCGT 2017): one
 // reciprocal and a dozen multiply-adds.
+// The f64 kernels, whose renders are compared with the CPU restatement path by path, build the
+// reference's basis instead.
 template <typename R>
 RRT_DEV V3<R> to_world(R sin_t, R cos_t, R sin_p, R cos_p, V3<R> w) {
+    if (sizeof(R) == 8) {  // local_coordinate_system, src/math.rs:162-172
+        const V3<R> a = Num<R>::abs(w.x) > R(0.9) ? mk<R>(0, 1, 0) : mk<R>(1, 0, 0);
+        const V3<R> u = normalize(cross(w, a));
+        const V3<R> v = normalize(cross(w, u));
+        const R cu = sin_t * cos_p, cv = sin_t * sin_p;
+        return mk<R>(u.x * cu + v.x * cv + w.x * cos_t, u.y * cu + v.y * cv + w.y * cos_t,
+                     u.z * cu + v.z * cv + w.z * cos_t);
+    }
     const R sign = w.z >= R(0) ? R(1) : R(-1);
     const R a = R(-1) * Num<R>::rcp(sign + w.z);
     const R b = w.x * w.y * a;

@@ -1,0 +1,65 @@
+"""The f64 device renderer against the oracle PATH BY PATH.
+
+The oracle can draw its random numbers from a restatement of the device's counter-based generator
+(oracle.c, "device numbers"); the f64 kernels build the reference's orthonormal basis
+(src/math.rs:162-172).  Both then trace the same paths for the same seed, and every pixel sum must
+agree to rounding: the whole loop of generate_camera_vertices (src/tracers/utils.rs:16-91) -- closest
+hit, emission, Russian roulette, the sampler's dimension contract, scatter, throughput -- is compared
+deterministically instead of statistically.
+
+What may differ: the device accumulates in f64 per work item and stores f32 (one rounding per item);
+a ray within an ulp of an edge, a Russian-roulette or Fresnel threshold can go the other way (the
+device's intersection tests are algebraically equal to the reference's, not bitwise), which changes
+that one pixel visibly -- the tests allow a handful of such pixels per image."""
+import numpy as np
+import pytest
+
+import scenes_util as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(api, be, O, cfg, flat, rc, max_bad):
+    sc = api.Scene(flat)
+    dev, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64))
+    ref, rst = O.render_accumulate(flat, rc.render_desc(), device_numbers=True)
+    assert st["samples"] == rst["samples"] and st["nonfinite"] == 0 and rst["nonfinite"] == 0
+    err = np.abs(dev.astype(np.float64) - ref)
+    tol = 4e-7 * np.abs(ref) + 1e-9  # f32 storage of (a few) f64 item sums
+    bad = int(np.any(err > tol, axis=-1).sum())
+    assert bad <= max_bad, (bad, float(err.max()))
+    # the same paths: the same number of closest-hit queries (the oracle also counts queries of paths whose
+    # throughput has dropped to exactly zero, which the device drops) and of scatter events per material
+    assert abs(st["rays"] - rst["rays_live"]) <= 8 * max(max_bad, 1)
+    return bad
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "smallpt"])
+def test_shipped_scenes_same_paths(gpu, O, cfg, scenes, name):
+    api, be = gpu
+    for rc in (cfg.stratified_config(96, 72, 8, 8, seed=17), cfg.stratified_config(40, 40, 5, 3, seed=18),
+               cfg.random_config(64, 48, 24, seed=19)):
+        bad = _compare(api, be, O, cfg, scenes[name], rc, max_bad=3)
+        print(name, rc.spp, "pixels off:", bad)
+
+
+def test_every_primitive_and_material_same_paths(gpu, O, cfg):
+    """Sphere, plane, triangle, quad and mesh faces; dielectric, Lambertian, Phong, mirror, emitter."""
+    api, be = gpu
+    flat = S.all_prims_scene()
+    for rc in (cfg.stratified_config(80, 60, 6, 6, min_depth=1, max_depth=8, seed=23),
+               cfg.random_config(48, 48, 16, min_depth=0, max_depth=5, seed=24)):
+        _compare(api, be, O, cfg, flat, rc, max_bad=4)
+
+
+def test_sample_range_shards_same_paths(gpu, O, cfg, cornell):
+    """A shard of the sample index range traces exactly those samples of the oracle's render."""
+    api, be = gpu
+    sc = api.Scene(cornell)
+    rc = cfg.stratified_config(48, 48, 4, 4, seed=29)
+    ref, _ = O.render_accumulate(cornell, rc.render_desc(), device_numbers=True)
+    acc = None
+    for lo, hi in ((0, 5), (5, 16)):
+        acc, _ = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64, sample_begin=lo, sample_end=hi), acc)
+    err = np.abs(acc.astype(np.float64) - ref)
+    assert int(np.any(err > 6e-7 * np.abs(ref) + 1e-9, axis=-1).sum()) <= 2
