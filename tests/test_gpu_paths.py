@@ -19,9 +19,9 @@ import scenes_util as S
 pytestmark = pytest.mark.gpu
 
 
-def _compare(api, be, O, cfg, flat, rc, max_bad):
+def _compare(api, be, O, cfg, flat, rc, max_bad, accel=None):
     sc = api.Scene(flat)
-    dev, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64))
+    dev, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64, accel=api.ACCEL_AUTO if accel is None else accel))
     ref, rst = O.render_accumulate(flat, rc.render_desc(), device_numbers=True)
     assert st["samples"] == rst["samples"] and st["nonfinite"] == 0 and rst["nonfinite"] == 0
     err = np.abs(dev.astype(np.float64) - ref)
@@ -50,6 +50,14 @@ def test_every_primitive_and_material_same_paths(gpu, O, cfg):
     for rc in (cfg.stratified_config(80, 60, 6, 6, min_depth=1, max_depth=8, seed=23),
                cfg.random_config(48, 48, 16, min_depth=0, max_depth=5, seed=24)):
         _compare(api, be, O, cfg, flat, rc, max_bad=4)
+
+
+def test_same_paths_through_the_tree(gpu, O, cfg, cornell):
+    """Closest hit through the LBVH instead of the scan: the same primitive and t for every ray, so the same image."""
+    api, be = gpu
+    _compare(api, be, O, cfg, cornell, cfg.stratified_config(64, 64, 4, 4, seed=31), max_bad=3, accel=api.ACCEL_LBVH)
+    _compare(api, be, O, cfg, S.all_prims_scene(), cfg.stratified_config(64, 48, 4, 4, max_depth=8, seed=32), max_bad=4,
+             accel=api.ACCEL_LBVH)
 
 
 def test_sample_range_shards_same_paths(gpu, O, cfg, cornell):
