@@ -365,7 +365,9 @@ typedef struct {
     size_t current_dimension;
     rng_t rng;
     uint64_t draws;
-    /* device_numbers != 0: the numbers come from the HIP backend's counter-based generator (below) */
+    /* device_numbers != 0: the numbers come from the HIP backend's counter-based generator (below);
+     * 2: as the f32 kernels see them (24-bit uniforms), and the two lobe samplers build the orthonormal
+     * basis those kernels build (to_world_f32_kernels) */
     int device_numbers;
     uint32_t seed_lo, seed_hi, pixel, pixkey, key, ctr, perm_mask;
 } sampler_t;
@@ -394,6 +396,7 @@ static uint32_t dev_permute(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
 }
 static double dev_uniform(sampler_t* s) {
     uint32_t bits = dev_mix32(s->key + (s->ctr++) * 0x9E3779B9U);
+    if (s->device_numbers == 2) return (double)(bits >> 8) * 5.9604644775390625e-8; /* 2^-24, the f32 kernels */
     return (double)bits * 2.3283064365386962890625e-10; /* 2^-32 */
 }
 static void dev_start_sample(sampler_t* s) {
@@ -545,6 +548,20 @@ static v3 mat_emission(const rrt_material* m) {
     return m->type == RRT_MAT_EMISSIVE ? ld3(m->rgb) : V(0, 0, 0);
 }
 
+/* spherical_to_world over the basis the f32 device kernels build around w (Duff et al., "Building an
+ * Orthonormal Basis, Revisited", JCGT 2017) instead of local_coordinate_system (src/math.rs:162-172).
+ * Both lobe samplers are symmetric in phi and phi is uniform, so the sampled distribution is the
+ * same; only used with the device's numbers (device_numbers == 2), to follow the f32 kernels' paths. */
+static v3 to_world_f32_kernels(double theta, double phi, v3 w) {
+    double sign = w.z >= 0.0 ? 1.0 : -1.0;
+    double a = -1.0 / (sign + w.z);
+    double b = w.x * w.y * a;
+    v3 u = V(1.0 + sign * w.x * w.x * a, sign * b, -sign * w.x);
+    v3 v = V(b, sign + w.y * w.y * a, -w.y);
+    double cu = sin(theta) * cos(phi), cv = sin(theta) * sin(phi), cw = cos(theta);
+    return V(u.x * cu + v.x * cv + w.x * cw, u.y * cu + v.y * cv + w.y * cw, u.z * cu + v.z * cv + w.z * cw);
+}
+
 /* Material::scatter; returns 0 for None.  src/material.rs:44-46 (Emissive),
  * 68-86 (Lambertian), 105-127 (PhongSpecular), 157-170 (IdealReflector),
  * 194-241 (IdealDielectric) */
@@ -558,7 +575,7 @@ static int mat_scatter(const rrt_material* m, const ray_t* ray_in, v3 hit_point,
         sampler_get_2d(sampler, &u, &v);
         double theta = acos(sqrt(1.0 - u));
         double phi = 2.0 * ORACLE_PI * v;
-        v3 nd = spherical_to_world(theta, phi, normal);
+        v3 nd = sampler->device_numbers == 2 ? to_world_f32_kernels(theta, phi, normal) : spherical_to_world(theta, phi, normal);
         out->o = hit_point; out->d = nd;
         *pdf = vdot(nd, normal) * FRAC_1_PI;
         return 1;
@@ -570,7 +587,7 @@ static int mat_scatter(const rrt_material* m, const ray_t* ray_in, v3 hit_point,
         sampler_get_2d(sampler, &u, &v);
         double theta = acos(pow(u, 1.0 / (shininess + 1.0)));
         double phi = 2.0 * ORACLE_PI * v;
-        v3 nd = spherical_to_world(theta, phi, reflected);
+        v3 nd = sampler->device_numbers == 2 ? to_world_f32_kernels(theta, phi, reflected) : spherical_to_world(theta, phi, reflected);
         out->o = hit_point; out->d = nd;
         *pdf = pow(vdot(nd, reflected), shininess) * (shininess + 1.0) * FRAC_1_PI * 0.5;
         return 1;
@@ -785,10 +802,11 @@ int oracle_render_accumulate(const rrt_scene_desc* scene, const rrt_render_desc*
     return render_accumulate_impl(scene, rd, rgb_sum, stats, n_threads, 0);
 }
 /* The same render with the numbers of the HIP backend's generator (see dev_mix32 above): the image the
- * f64 device kernels must reproduce pixel by pixel for the same seed. */
+ * f64 device kernels must reproduce pixel by pixel for the same seed (f32_kernels = 0), or the one the
+ * f32 kernels follow up to their rounding (f32_kernels = 1: 24-bit uniforms, their lobe basis). */
 int oracle_render_accumulate_device_numbers(const rrt_scene_desc* scene, const rrt_render_desc* rd,
-                                            double* rgb_sum, rrt_stats* stats, int n_threads) {
-    return render_accumulate_impl(scene, rd, rgb_sum, stats, n_threads, 1);
+                                            double* rgb_sum, rrt_stats* stats, int n_threads, int f32_kernels) {
+    return render_accumulate_impl(scene, rd, rgb_sum, stats, n_threads, f32_kernels ? 2 : 1);
 }
 static int render_accumulate_impl(const rrt_scene_desc* scene, const rrt_render_desc* rd,
                                   double* rgb_sum, rrt_stats* stats, int n_threads, int device_numbers) {

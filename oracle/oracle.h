@@ -20,9 +20,10 @@ int oracle_trace_primary(const rrt_scene_desc* scene, size_t n, const double* u,
                          int32_t* object_id, int32_t* prim_id, double* t);
 int oracle_render_accumulate(const rrt_scene_desc* scene, const rrt_render_desc* rd,
                              double* rgb_sum, rrt_stats* stats, int n_threads);
-/* the same render drawing its random numbers from the restated generator of the HIP backend */
+/* the same render drawing its random numbers from the restated generator of the HIP backend; f32_kernels: as the
+ * f32 kernels see them (24-bit uniforms) and with their lobe basis */
 int oracle_render_accumulate_device_numbers(const rrt_scene_desc* scene, const rrt_render_desc* rd,
-                             double* rgb_sum, rrt_stats* stats, int n_threads);
+                             double* rgb_sum, rrt_stats* stats, int n_threads, int f32_kernels);
 int oracle_postprocess(const double* rgb_sum, uint64_t spp_divisor, const rrt_post_desc* post,
                        uint32_t width, uint32_t height, uint8_t* rgb8, double* rgb_linear);
 

@@ -44,7 +44,7 @@ def lib():
         L.oracle_trace_primary.argtypes = [C.POINTER(_abi.SceneDesc), C.c_size_t, _dp, _dp, _i32p, _i32p, _dp]
         L.oracle_render_accumulate.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.RenderDesc), _dp,
                                                C.POINTER(_abi.Stats), C.c_int]
-        L.oracle_render_accumulate_device_numbers.argtypes = L.oracle_render_accumulate.argtypes
+        L.oracle_render_accumulate_device_numbers.argtypes = L.oracle_render_accumulate.argtypes + [C.c_int]
         L.oracle_postprocess.argtypes = [_dp, C.c_uint64, C.POINTER(_abi.PostDesc), C.c_uint32, C.c_uint32,
                                          C.POINTER(C.c_uint8), _dp]
         L.oracle_trace_samples.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.RenderDesc), C.c_size_t,
@@ -192,14 +192,18 @@ def trace_primary(scene, u, v):
 
 def render_accumulate(scene, render_desc, n_threads=0, device_numbers=False):
     """-> (rgb_sum [H,W,3] f64, stats dict).  device_numbers: draw the random numbers from the restated
-    generator of the HIP backend instead of the oracle's own, so that both trace the same paths."""
+    generator of the HIP backend instead of the oracle's own, so that both trace the same paths (True or "f64":
+    the numbers of the f64 kernels; "f32": those of the f32 kernels, and their lobe basis)."""
     if n_threads <= 0:
         n_threads = os.cpu_count() or 1
     rgb = np.zeros((render_desc.height, render_desc.width, 3))
     st = _abi.Stats()
     desc = scene.desc()
-    fn = lib().oracle_render_accumulate_device_numbers if device_numbers else lib().oracle_render_accumulate
-    rc = fn(C.byref(desc), C.byref(render_desc), rgb.ctypes.data_as(_dp), C.byref(st), n_threads)
+    args = [C.byref(desc), C.byref(render_desc), rgb.ctypes.data_as(_dp), C.byref(st), n_threads]
+    if device_numbers:
+        rc = lib().oracle_render_accumulate_device_numbers(*args, 1 if device_numbers == "f32" else 0)
+    else:
+        rc = lib().oracle_render_accumulate(*args)
     if rc != 0:
         raise ValueError("oracle_render_accumulate rejected the configuration")
     out = st.as_dict()
