@@ -99,3 +99,22 @@ def test_f32_kernels_follow_the_same_paths(gpu, O, cfg, scenes, name):
     for pipeline, label in ((api.PIPELINE_FUSED, "fused"), (api.PIPELINE_WAVEFRONT, "wavefront")):
         frac, rel_rays = _follow(api, be, O, scenes[name], rc, pipeline, name + " " + label)
         assert frac <= 0.005 and rel_rays <= 1e-4
+
+
+@pytest.mark.parametrize("case", ["cornell_full_image", "cornell_full_spp", "smallpt_full_image", "cornell_cube"])
+def test_f32_kernels_at_benchmark_shapes(gpu, O, cfg, scenes, case):
+    """The benchmark configurations with ONE of their two sizes reduced so that the oracle finishes in a second:
+    the full 500x500 / 1024x768 images at 4 spp, and all 16384 samples per pixel (128 x 128 strata, what the
+    headline number is quoted on) of a 16x16 image."""
+    import os
+    from conftest import ROOT
+    api, be = gpu
+    flat, rc = {
+        "cornell_full_image": (scenes["cornell_box"], cfg.stratified_config(500, 500, 2, 2, seed=51)),
+        "cornell_full_spp": (scenes["cornell_box"], cfg.stratified_config(16, 16, 128, 128, seed=52)),
+        "smallpt_full_image": (scenes["smallpt"], cfg.stratified_config(1024, 768, 2, 2, seed=53)),
+        "cornell_cube": (cfg.load_scene(os.path.join(ROOT, "configs", "cornell_cube", "scene.toml")),
+                         cfg.stratified_config(256, 256, 8, 8, seed=54)),
+    }[case]
+    frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_AUTO, case)
+    assert frac <= 0.005 and rel_rays <= 1e-4
