@@ -118,3 +118,20 @@ def test_f32_kernels_at_benchmark_shapes(gpu, O, cfg, scenes, case):
     }[case]
     frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_AUTO, case)
     assert frac <= 0.005 and rel_rays <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "smallpt"])
+def test_committed_renders(gpu, cfg, scenes, name):
+    """The device against tests/golden/paths.npz (made by tools/make_golden.py from the oracle): no oracle at run time."""
+    import os
+    from conftest import GOLDEN
+    api, be = gpu
+    g = np.load(os.path.join(GOLDEN, "paths.npz"))
+    sc = api.Scene(scenes[name])
+    rc = cfg.stratified_config(32, 32, 4, 4, seed=61)
+    for mode, prec, rel, max_bad in (("f64", api.PRECISION_F64, 4e-7, 1), ("f32", api.PRECISION_F32, 2e-5, 5)):
+        dev, st = be.render_accumulate(sc, rc.render_desc(precision=prec))
+        ref = g[f"{name}_{mode}"]
+        bad = int(np.any(np.abs(dev - ref) > rel * np.abs(ref) + 1e-6, axis=-1).sum())
+        assert bad <= max_bad, (mode, bad)
+        assert abs(st["rays"] - int(g[f"{name}_{mode}_rays"])) <= 8 * max_bad

@@ -34,3 +34,16 @@ def test_agrees_with_own_generator(O, cfg, cornell):
     # the light (radiance 100 per covered sample) has the same coverage with both generators
     lit_a, lit_b = (a[..., 1] > 50 * rc.spp).sum(), (b[..., 1] > 50 * rc.spp).sum()
     assert abs(int(lit_a) - int(lit_b)) <= 2
+
+
+def test_reproduces_the_committed_renders(O, cfg, scenes):
+    """tests/golden/paths.npz (tools/make_golden.py): the renders the GPU tests hold the device kernels to."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "paths.npz"))
+    rc = cfg.stratified_config(32, 32, 4, 4, seed=61)
+    for name, flat in scenes.items():
+        for mode in ("f64", "f32"):
+            rgb, st = O.render_accumulate(flat, rc.render_desc(), device_numbers=mode)
+            assert np.allclose(rgb, g[f"{name}_{mode}"], rtol=1e-9, atol=1e-12)  # (libm may differ in the last bit)
+            assert st["rays_live"] == int(g[f"{name}_{mode}_rays"])

@@ -10,6 +10,12 @@ images.npz         per scene: 48x48 radiance means (float32, linear, before
                    post-processing) of two oracle renders with different seeds
                    at 32x32 = 1024 spp, used to calibrate the image-RMSE gate.
 
+paths.npz          per scene: the pixel SUMS (float64) of 32x32 renders at 4x4 = 16 spp,
+                   seed 61, with the oracle drawing the numbers of the HIP backend's
+                   generator ("f64": what the f64 kernels must reproduce pixel by pixel;
+                   "f32": what the f32 kernels follow up to their rounding), plus the
+                   oracle's count of closest-hit queries made with non-zero throughput.
+
 The reference itself cannot produce these (no Rust toolchain here, no
 deterministic seed in the reference); the oracle is cross-checked against an
 independent numpy restatement in tests/test_oracle_scene.py.
@@ -49,7 +55,16 @@ def main():
             rc = config.stratified_config(48, 48, 32, 32, seed=seed)
             rgb, _ = O.render_accumulate(flat, rc.render_desc())
             img[f"{name}_seed{seed}"] = (rgb / rc.spp).astype(np.float32)
+    paths = {}
+    for name in SCENES:
+        flat = config.load_scene(os.path.join(ROOT, "configs", name, "scene.toml"))
+        rc = config.stratified_config(32, 32, 4, 4, seed=61)
+        for mode in ("f64", "f32"):
+            rgb, st = O.render_accumulate(flat, rc.render_desc(), device_numbers=mode)
+            paths[f"{name}_{mode}"] = rgb
+            paths[f"{name}_{mode}_rays"] = np.int64(st["rays_live"])
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "paths.npz"), **paths)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "primary_hits.npz"), **out)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "images.npz"), **img)
 
