@@ -135,3 +135,46 @@ def test_committed_renders(gpu, cfg, scenes, name):
         bad = int(np.any(np.abs(dev - ref) > rel * np.abs(ref) + 1e-6, axis=-1).sum())
         assert bad <= max_bad, (mode, bad)
         assert abs(st["rays"] - int(g[f"{name}_{mode}_rays"])) <= 8 * max_bad
+
+
+def _two_mesh_scene(n_tri_each):
+    """Two displaced spheres of triangles -- glass (ior 1.5) and Phong, the materials of the million-triangle
+    benchmark scene -- over a Lambertian plane inside an emissive sphere."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_mesh
+    from rustraytracer_amd import _abi, config
+    parts = []
+    for k, (centre, seed) in enumerate((((-1.1, 0.0, -4.0), 3), ((1.1, 0.1, -4.5), 4))):
+        v, _, f = make_mesh.displaced_sphere(n_tri_each, radius=1.0, bump=0.15, seed=seed)
+        tri = v[f].astype(np.float64) + np.array(centre)
+        p = np.zeros(len(f), dtype=_abi.PRIM_DTYPE)
+        p["type"], p["object_id"], p["prim_id"] = _abi.PRIM_TRIANGLE, k, np.arange(len(f))
+        p["v"][:, :9] = tri.reshape(len(f), 9)
+        parts.append(p)
+    rest = np.zeros(2, dtype=_abi.PRIM_DTYPE)
+    rest["type"][0], rest["object_id"][0] = _abi.PRIM_SPHERE, 2
+    rest["v"][0, :4] = [0, 0, 0, 40.0]
+    rest["type"][1], rest["object_id"][1] = _abi.PRIM_PLANE, 3
+    rest["v"][1, :6] = [0, -1.3, 0, 0, 1, 0]
+    m = np.zeros(4, dtype=_abi.MATERIAL_DTYPE)
+    for i, (typ, rgb, param) in enumerate(((_abi.MAT_DIELECTRIC, (0, 0, 0), 1.5), (_abi.MAT_PHONG, (0.8, 0.7, 0.3), 25.0),
+                                           (_abi.MAT_EMISSIVE, (1.0, 0.9, 0.8), 0.0), (_abi.MAT_LAMBERTIAN, (0.6, 0.6, 0.6), 0.0))):
+        m["type"][i], m["rgb"][i], m["param"][i] = typ, rgb, param
+    cam = config.perspective_camera((0, 0.3, 0), (0, 0, -4), (0, 1, 0), 45.0, 1.0)
+    return config.FlatScene(cam, np.concatenate(parts + [rest]), m)
+
+
+def test_mesh_scene_through_tree_and_wavefront_same_paths(gpu, O, cfg):
+    """20 000 triangles: AUTO takes the LBVH and, in f32, the wavefront pipeline (persistent tree-walk kernel, ray
+    queues, compaction); the oracle scans every triangle for every ray.  Same paths, so the same pixels."""
+    api, be = gpu
+    flat = _two_mesh_scene(10000)
+    assert flat.n_prims > 15000
+    rc = cfg.stratified_config(64, 64, 2, 2, max_depth=8, seed=71)
+    bad = _compare(api, be, O, cfg, flat, rc, max_bad=4)                      # f64: fused kernel + tree
+    frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_AUTO, "two meshes")  # f32: wavefront + tree
+    print("f64 pixels off:", bad)
+    assert frac <= 0.01 and rel_rays <= 3e-4
