@@ -95,10 +95,10 @@ def test_f32_kernels_follow_the_same_paths(gpu, O, cfg, scenes, name):
     off by a whole sample; everywhere else the sums agree to f32 rounding.  Measured at 64 spp: no pixel of the Cornell
     box, 4 of 6912 of smallpt (sphere silhouettes).  Gate: 0.5 % of the pixels, closest-hit query counts within 1e-4."""
     api, be = gpu
-    rc = cfg.stratified_config(96, 72, 8, 8, seed=41)
-    for pipeline, label in ((api.PIPELINE_FUSED, "fused"), (api.PIPELINE_WAVEFRONT, "wavefront")):
-        frac, rel_rays = _follow(api, be, O, scenes[name], rc, pipeline, name + " " + label)
-        assert frac <= 0.005 and rel_rays <= 1e-4
+    for rc in (cfg.stratified_config(96, 72, 8, 8, seed=41), cfg.random_config(64, 48, 31, min_depth=1, max_depth=9, seed=42)):
+        for pipeline, label in ((api.PIPELINE_FUSED, "fused"), (api.PIPELINE_WAVEFRONT, "wavefront")):
+            frac, rel_rays = _follow(api, be, O, scenes[name], rc, pipeline, "%s %s %d spp" % (name, label, rc.spp))
+            assert frac <= 0.005 and rel_rays <= 1e-4
 
 
 @pytest.mark.parametrize("case", ["cornell_full_image", "cornell_full_spp", "smallpt_full_image", "cornell_cube"])
