@@ -274,13 +274,13 @@ private:
                 fail("unsupported value '" + tok_in + "' (dates are not supported)");
         }
         char* end = nullptr;
+        std::string digits = tok;  // `end` points into tok or digits: both outlive the check below
         if (is_float && body.compare(0, 2, "0x") != 0) {
             v.kind = Value::FLOAT;
             v.f = std::strtod(tok.c_str(), &end);
         } else {
             v.kind = Value::INT;
             int base = 10;
-            std::string digits = tok;
             if (body.compare(0, 2, "0x") == 0) { base = 16; digits = body.substr(2); }
             else if (body.compare(0, 2, "0o") == 0) { base = 8; digits = body.substr(2); }
             else if (body.compare(0, 2, "0b") == 0) { base = 2; digits = body.substr(2); }

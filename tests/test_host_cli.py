@@ -11,7 +11,8 @@ import pytest
 from conftest import ROOT
 from rustraytracer_amd import _abi, config
 
-RRT = os.path.join(ROOT, "rustraytracer_amd", "host", "rrt")
+# RRT_HOST_BINARY: another build of the host to run these tests on (the sanitizer build, see the last test)
+RRT = os.path.abspath(os.environ.get("RRT_HOST_BINARY", os.path.join(ROOT, "rustraytracer_amd", "host", "rrt")))
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -236,3 +237,26 @@ def test_image_writer(tmp_path):
         assert np.array_equal(np.asarray(Image.open(out).convert("RGB")), expect)
     r = run("--self-test-image", str(tmp_path / "g.bmp"))
     assert r.returncode == 101 and "unsupported image format" in r.stderr
+
+
+def test_host_and_oracle_under_sanitizers(tmp_path):
+    """The whole of this file again on a build of the host with AddressSanitizer + UndefinedBehaviorSanitizer (every
+    parser, loader and writer path above, malformed inputs included), and the oracle's renderer on a driver built the
+    same way (oracle/san_check.c)."""
+    if os.environ.get("RRT_HOST_BINARY"):
+        pytest.skip("already running on another build of the host")
+    import sys
+    host = os.path.join(ROOT, "rustraytracer_amd", "host")
+    san = os.path.join(ROOT, "tests", "c_abi", "rrt_san")
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O1", "-g", "-std=c++17", "-Wall", "-Wextra",
+                           "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           "rrt_main.cpp", "-o", san, "-pthread", "-L" + os.path.join(ROOT, "rustraytracer_amd", "csrc"), "-lrrt_hip",
+                           "-lz", "-Wl,-rpath,$ORIGIN/../../rustraytracer_amd/csrc"], cwd=host)
+    env = dict(os.environ, RRT_HOST_BINARY=san)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.abspath(__file__)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout and "skipped" in r.stdout
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "san_check"])
+    r = subprocess.run([os.path.join(ROOT, "oracle", "san_check")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "san_check ok" in r.stdout, r.stdout + r.stderr
