@@ -86,7 +86,7 @@ for k in sorted(kern, key=lambda k: -float(kern[k]["TotalDurationNs"])):
         per = 1024 * total_s * clock * 1e9 / c['SQ_INSTS_VALU']
         lines.append(f"* VALU issue: one wave64 VALU instruction per {per:.2f} cycles per SIMD; a full wave issues back to back "
                      f"every 4 cycles (tools/ubench/valu_rate.hip) -> {4 / per:.2f} instructions per 4-cycle slot"
-                     + (" (above 1: instructions with few active lanes are observed to issue faster than a full wave)" if per < 4 else ""))
+                     + (" (above 1: integer shift/xor/add instructions issue every ~3.6 cycles, tools/ubench/valu_rate.hip; the EXEC mask makes no difference, tools/ubench/exec_rate.hip)" if per < 4 else ""))
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
         wc = c["SQ_WAVE_CYCLES"]
         lines.append(f"* wave-cycle shares: waiting on s_waitcnt {c['SQ_WAIT_ANY']/wc:.2f}, issue stalls "
