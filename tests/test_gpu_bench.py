@@ -43,3 +43,36 @@ def test_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "rehearsal" in d
     assert d["config"]["samples_per_step"] == 2 * 1024 * 768 * 64  # both ranks' 64 sample indices of every pixel
     assert "cpu_baseline" not in d  # timed on rank 0 at N = 1 only
+
+
+RCCL_PROBE = r'''
+import os, sys
+sys.path.insert(0, os.environ["RRT_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from rustraytracer_amd import api, config
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))  # what bench.py does for N > 1
+be = api.Backend(0)
+be.set_stream(torch.cuda.current_stream().cuda_stream)
+sc = api.Scene(config.load_scene(os.path.join(os.environ["RRT_ROOT"], "configs", "smallpt", "scene.toml")))
+rc = config.stratified_config(64, 48, 4, 4)
+acc = torch.zeros((48, 64, 3), dtype=torch.float32, device="cuda")
+be.render_accumulate(sc, rc.render_desc(), acc)
+before = acc.clone()
+dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)   # RCCL kernels on torch's stream, after the render on the same stream
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(acc, before) and float(t.item()) == 1.5 and float(acc.sum()) > 0
+dist.destroy_process_group()
+print("rccl probe ok")
+'''
+
+
+def test_rccl_process_group_of_one():
+    """The multi-GPU bench path minus the second GPU: an RCCL ("nccl") process group of one rank on this box, the
+    sum-reduce and the max all-reduce bench.py issues, on an accumulator the library has just written on torch's stream."""
+    env = dict(os.environ, RRT_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", RCCL_PROBE], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "rccl probe ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
