@@ -59,6 +59,10 @@ typedef enum rrt_material_type {
 /* src/sampler.rs:168-173 */
 typedef enum rrt_sampler_type { RRT_SAMPLER_RANDOM = 0, RRT_SAMPLER_STRATIFIED = 1 } rrt_sampler_type;
 
+/* F32 is the product path.  F64 computes in the reference's arithmetic type (src/math.rs:4-8) and builds the
+ * reference's orthonormal basis in the lobe samplers (src/math.rs:162-172; F32 uses a cheaper one with the same
+ * distribution): for a given seed it traces, sample by sample, the paths a CPU implementation of the reference
+ * traces when it draws the same random numbers. */
 typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_precision;
 
 /* How closest-hit walks the primitives.  AUTO = wave-uniform linear scan for
