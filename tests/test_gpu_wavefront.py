@@ -93,3 +93,19 @@ def test_wavefront_rejects_what_it_cannot_do(gpu, cfg, cornell):
     rc = cfg.stratified_config(8, 8, 2, 2, max_depth=0)
     rgb, st = be.render_accumulate(sc, rc.render_desc(pipeline=api.PIPELINE_WAVEFRONT))
     assert st["rays"] == 0 and not rgb.any()
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 256, 256), (4096, 2048, 1, 1), (3, 1000, 2, 2), (1000, 3, 1, 3)])
+def test_extreme_image_shapes_both_pipelines(gpu, cfg, shape):
+    """One pixel with 65536 samples, eight million pixels with one sample, images one wave wide or tall: every
+    (pixel, sample) is traced exactly once by either pipeline (furnace scene: every sample returns exactly L)."""
+    import scenes_util as S
+    api, be = gpu
+    w, h, xs, ys = shape
+    sc = api.Scene(S.furnace())
+    rc = cfg.stratified_config(w, h, xs, ys)
+    for pipeline in (api.PIPELINE_FUSED, api.PIPELINE_WAVEFRONT):
+        rgb, st = be.render_accumulate(sc, rc.render_desc(pipeline=pipeline))
+        assert st["samples"] == w * h * xs * ys and st["rays"] == st["samples"] and st["nonfinite"] == 0
+        want = np.float64(S.L) * (xs * ys)
+        assert np.allclose(rgb, np.broadcast_to(want, rgb.shape), rtol=1e-6)  # sums of up to 512 chunk sums in f32
