@@ -178,3 +178,41 @@ def test_mesh_scene_through_tree_and_wavefront_same_paths(gpu, O, cfg):
     frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_AUTO, "two meshes")  # f32: wavefront + tree
     print("f64 pixels off:", bad)
     assert frac <= 0.01 and rel_rays <= 3e-4
+
+
+def _nasty_scene():
+    """Coincident surfaces with different materials (the scan order decides which one a ray sees), a zero-area
+    triangle, a quad a millimetre above a plane, an albedo above one, Phong exponents 0 and 1000, glass with index 1."""
+    from rustraytracer_amd import _abi
+    q = [[-2, -1, -6], [0, -1, -6], [0, 1, -6], [-2, 1, -6]]
+    prims = [
+        (3, 0, 0, q), (3, 1, 0, q),                                        # the same quad twice: the later object wins the tie
+        (2, 2, 0, [[0.5, -1, -5], [2.5, -1, -5], [1.5, 1, -5]]),
+        (2, 3, 0, [[0.5, -1, -5], [2.5, -1, -5], [1.5, 1, -5]]),           # the same triangle twice: the earlier one wins
+        (2, 2, 1, [[0, 0, -3], [0, 0, -3], [0, 0, -3]]),                   # zero area
+        (1, 4, 0, [0, -1, 0, 0, 1, 0]),                                     # floor plane ...
+        (3, 5, 0, [[-3, -0.999, -2], [3, -0.999, -2], [3, -0.999, -8], [-3, -0.999, -8]]),  # ... and a quad a millimetre above it
+        # (a quad IN the plane would be a tie between two different formulas for t, which rounding decides)
+        (0, 6, 0, [1.8, 0.2, -3.5, 0.7]),                                   # glass with ior 1
+        (0, 7, 0, [-1.2, -0.3, -3.0, 0.6]),                                 # Phong, exponent 1000
+        (0, 8, 0, [0, 0, 0, 25.0]),                                         # light all around (the camera is inside)
+    ]
+    mats = [(_abi.MAT_LAMBERTIAN, (0.2, 0.9, 0.2), 0.0), (_abi.MAT_LAMBERTIAN, (1.3, 0.4, 0.4), 0.0),
+            (_abi.MAT_REFLECTOR, (0, 0, 0), 0.0), (_abi.MAT_LAMBERTIAN, (0.1, 0.1, 0.9), 0.0),
+            (_abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0), (_abi.MAT_PHONG, (0.9, 0.9, 0.9), 0.0),
+            (_abi.MAT_DIELECTRIC, (0, 0, 0), 1.0), (_abi.MAT_PHONG, (0.8, 0.8, 0.8), 1000.0),
+            (_abi.MAT_EMISSIVE, (0.9, 1.0, 1.1), 0.0)]
+    return S.make_scene(prims, mats, look_from=(0, 0.4, 1.5), look_at=(0, 0, -5), vfov=50.0, aspect=4 / 3)
+
+
+def test_ties_and_degenerate_inputs_same_paths(gpu, O, cfg):
+    api, be = gpu
+    flat = _nasty_scene()
+    rc = cfg.stratified_config(96, 72, 4, 4, min_depth=1, max_depth=10, seed=81)
+    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH):
+        bad = _compare(api, be, O, cfg, flat, rc, max_bad=6, accel=accel)
+        print("accel", accel, "f64 pixels off:", bad)
+    frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_FUSED, "nasty fused")
+    assert frac <= 0.005 and rel_rays <= 1e-4
+    frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_WAVEFRONT, "nasty wavefront")
+    assert frac <= 0.005 and rel_rays <= 1e-4
