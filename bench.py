@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Cornell Box 500x500, stratified 16384 spp per GPU (MCPT, depth 2/6).
+"""Headline benchmark: Cornell Box 500x500 at 16384 spp (stratified 128x128), MCPT depth 2/6, on N GPUs.
 
-    python bench.py --gpus N --steps K --warmup W [--workload NAME] [--pipeline auto|fused|wavefront]
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak] [--workload NAME]
+                    [--pipeline auto|fused|wavefront] [--precision f32|f64]
 
-One step = one full pass of the hot path: every rank renders its sample indices
-of every pixel into an HBM-resident accumulator (rrt_render_accumulate), the
-accumulators are summed on rank 0 (RCCL reduce, N > 1) and rank 0 runs the
-fused post-process.  Weak scaling: per-GPU work is fixed, the image gets
-N x (samples per GPU) samples per pixel.  Rank 0 prints ONE JSON line.
+One step = one full pass of the hot path over one image: every rank renders its sample indices of
+every pixel into an HBM-resident accumulator (rrt_render_accumulate), the accumulators are summed on
+rank 0 (one RCCL reduce, N > 1) and rank 0 runs the post-process.  Rank 0 prints ONE JSON line.
+
+--scaling strong (default): ONE image at the workload's samples per pixel (16384 for the headline), its
+    sample indices split over the ranks (distributed.shard_range) -- one image, one spp, as the
+    reference renders it (src/renderer.rs:101-128 splits the same image into tiles over its threads).
+--scaling weak: every rank traces the workload's full sample count; the image gets N times as many.
+
+Started without a launcher (`python bench.py --gpus 8`), the script starts its N ranks itself as fresh
+child processes through torch.distributed.run, before it touches a GPU, relays rank 0's line and exits
+with the launcher's status.  Started by a launcher (WORLD_SIZE set), it is one of the ranks.
 
 Workloads (the default is the one the headline metric is quoted on):
-    cornell       configs/cornell_box, 500x500, 128x128 strata per GPU
-    smallpt       configs/smallpt, 1024x768, 128x128 strata per GPU
-    cornell_cube  configs/cornell_cube (Cornell box + assets/test.ply), 1024x1024, 64x64 strata per GPU
+    cornell       configs/cornell_box, 500x500, 128x128 strata
+    smallpt       configs/smallpt, 1024x768, 128x128 strata
+    cornell_cube  configs/cornell_cube (Cornell box + assets/test.ply), 1024x1024, 64x64 strata
     mesh_1m       configs/mesh_1m (Cornell shell + two generated 500k-triangle meshes), 3840x2160,
-                  32x32 strata per GPU; closest hit through the GPU-built LBVH
+                  32x32 strata; closest hit through the GPU-built LBVH
 """
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,12 +44,15 @@ PEAK_FP64_VALU_TFLOPS = 78.6   # vector FP64: one FMA per lane and clock
 FLOPS_PER_PRIM_TEST = {"sphere": 21, "plane": 14, "triangle": 51, "quad": 52}
 FLOPS_PER_BOUNCE = [0, 110, 140, 30, 90]  # emissive, lambertian, phong, reflector, dielectric
 FLOPS_RAYGEN = 25
-
+# What the kernels execute per primitive test (plane-form tests, rrt_device.hpp): counted from the source the same
+# way, comparisons and selects excluded.  sphere: 3 sub + 5 dot + 6 perp + 5 dot + 1 sub + sqrt + 2; plane: 5 + 6 + rcp
+# + mul; triangle / parallelogram: 5 (n.d) + 6 (n.o) + rcp + mul + 6 (P) + 6 + 6 (two coefficients) + 3-5 (edge terms).
+EXECUTED_FLOPS_PER_PRIM_TEST = {"sphere": 24, "plane": 13, "triangle": 36, "quad": 36}
 
 FLOPS_PER_NODE_TEST = 24  # one ray/box slab test
 QUEUE_BYTES_PER_RAY = 88  # wavefront pipeline: ray 24 B + throughput 12 B + ids 8 B, written and read once per bounce
 
-# name -> (scene file, width, height, strata per axis per GPU, CPU-baseline strata per axis or None)
+# name -> (scene file, width, height, strata per axis, CPU-baseline strata per axis or (w, h, side))
 WORKLOADS = {
     "cornell": ("configs/cornell_box/scene.toml", 500, 500, 128, 32),
     "smallpt": ("configs/smallpt/scene.toml", 1024, 768, 128, 16),
@@ -46,22 +60,68 @@ WORKLOADS = {
     # the reference scans 1 M triangles per ray (~10 ms each on a host core): its sample is 64x36 pixels at 4 spp
     "mesh_1m": ("configs/mesh_1m/scene.toml", 3840, 2160, 32, (64, 36, 2)),
 }
+METRIC_NAMES = {"cornell": "Cornell Box 500x500", "smallpt": "smallpt 1024x768",
+                "cornell_cube": "Cornell Box + test.ply 1024x1024", "mesh_1m": "1M-triangle mesh scene 3840x2160"}
 
 
-def scene_flops(flat):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: one image at the workload's spp, sample indices split over the GPUs; "
+                         "weak: the workload's spp per GPU")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell")
+    ap.add_argument("--pipeline", choices=["auto", "fused", "wavefront"], default="auto")
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32",
+                    help="f32 is the product path; f64 runs the same kernels in the reference's arithmetic type")
+    ap.add_argument("--spp-side", type=int, default=0, help="strata per axis (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------- launcher (parent process)
+def launch_ranks(n, argv):
+    """Runs the N ranks of this script as fresh child processes (torch.distributed.run, one per GPU) and relays rank 0's
+    JSON line.  The parent never imports torch and never touches a GPU; the children start from a clean process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC, which RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    for l in proc.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if proc.returncode != 0:
+        print("bench.py: a rank failed (launcher exit status %d)" % proc.returncode, file=sys.stderr)
+        return proc.returncode
+    if not lines:
+        print("bench.py: the ranks printed no result line", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------- roofline bookkeeping
+def scene_flops(flat, table=FLOPS_PER_PRIM_TEST):
     """(flops of a linear scan of the whole scene, mean flops of one primitive test)."""
     import numpy as np
 
     names = ["sphere", "plane", "triangle", "quad"]
     counts = np.bincount(flat.prims["type"], minlength=4)
-    scan = int(sum(FLOPS_PER_PRIM_TEST[names[k]] * int(counts[k]) for k in range(4)))
+    scan = int(sum(table[names[k]] * int(counts[k]) for k in range(4)))
     return scan, scan / max(int(counts.sum()), 1)
 
 
-def algorithmic_flops(stats, flat):
+def algorithmic_flops(stats, flat, table=FLOPS_PER_PRIM_TEST):
     """Closest-hit arithmetic actually asked for (every primitive per ray in a linear scan; node and
     primitive tests from the device counters through the tree) + shading + ray generation."""
-    scan, per_prim = scene_flops(flat)
+    scan, per_prim = scene_flops(flat, table)
     if stats["node_tests"]:
         hit = stats["node_tests"] * FLOPS_PER_NODE_TEST + stats["prim_tests"] * per_prim
     else:
@@ -69,8 +129,56 @@ def algorithmic_flops(stats, flat):
     return hit + sum(b * f for b, f in zip(stats["bounces"], FLOPS_PER_BOUNCE)) + stats["samples"] * FLOPS_RAYGEN
 
 
+def measured_traffic(workload, wavefront, precision):
+    """HBM-side bytes per launch from the kept PMC passes (profiles/hbm_traffic.json, written by
+    tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE runs): a kept figure of an earlier
+    profile of the same kernel and workload, not a counter of this run.  -> (bytes or None, source)."""
+    if precision != "f32":
+        return None, "no PMC pass kept for the f64 kernels"
+    key = workload + ("_wavefront" if wavefront and workload != "mesh_1m" else "")
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            table = json.load(f)
+    except Exception as e:  # noqa: BLE001
+        return None, "profiles/hbm_traffic.json unreadable: %s" % e
+    ent = table.get("workloads", {}).get(key)
+    if ent is None and key == "cornell" and "bytes_per_launch" in table:  # file layout of the first round
+        ent = table
+    if ent is None:
+        return None, "no PMC pass kept for %s" % key
+    return ent.get("bytes_per_launch"), "kept PMC figure, not measured in this run: %s (%s)" % (ent.get("source"), ent.get("note", ""))
+
+
+# ---------------------------------------------------------------------------- CPU baseline
+def usable_cpus():
+    """Logical CPUs this job may use: the affinity mask, cut to the cgroup's CPU quota and to the share the box
+    announces through OMP_NUM_THREADS (on a shared GPU host os.cpu_count() reports the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(n, 1)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    return "unknown"
+
+
 def cpu_baseline(flat, name, width, height, side, threads):
-    """The f64 CPU restatement of the reference renderer (oracle/), timed on a bounded sample."""
+    """The f64 CPU restatement of the reference renderer (oracle/), timed on a bounded sample, with
+    `parallelism = 0` semantics: every CPU the job may use (src/renderer.rs:74-78)."""
     from oracle import oracle_py as O
     from rustraytracer_amd import config
 
@@ -83,46 +191,40 @@ def cpu_baseline(flat, name, width, height, side, threads):
         "unit": "Msamples/s",
         "mrays_per_s": st["rays"] / dt / 1e6,
         "cores": threads,
+        "host_logical_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(),
         "kind": "port",
         "sample": "%s %dx%d stratified %dx%d = %d spp (%.4g M samples), f64 C restatement of the reference "
-                  "renderer (linear scan of every primitive per ray), 16x16 tiles over %d threads, %.1f s"
-                  % (name, width, height, side, side, side * side, st["samples"] / 1e6, threads, dt),
+                  "renderer (linear scan of every primitive per ray), 16x16 tiles over %d threads = every CPU "
+                  "this job may use (the host has %d logical CPUs), %.1f s"
+                  % (name, width, height, side, side, side * side, st["samples"] / 1e6, threads, os.cpu_count() or 0, dt),
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell")
-    ap.add_argument("--pipeline", choices=["auto", "fused", "wavefront"], default="auto")
-    ap.add_argument("--precision", choices=["f32", "f64"], default="f32",
-                    help="f32 is the product path; f64 runs the same kernels in the reference's arithmetic type")
-    ap.add_argument("--spp-side", type=int, default=0, help="strata per axis per GPU (default: the workload's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import numpy as np
+# ---------------------------------------------------------------------------- one rank
+def run_rank(args):
+    import numpy as np  # noqa: F401
     import torch
 
-    from rustraytracer_amd import api, config, distributed as D
+    from rustraytracer_amd import config, distributed as D
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-        args.gpus = world
-    if not torch.cuda.is_available():
+    args.gpus = world
+    # RRT_BENCH_REHEARSAL=1: every rank on GPU 0, gloo instead of RCCL -- the multi-rank code path (shards, reduce,
+    # max-over-ranks timing) on a one-GPU box.  RRT_BENCH_REHEARSAL=plumbing: no GPU at all -- launch, process group,
+    # shard plan and reduce only, with each rank's accumulator filled with its sample count instead of rendered.
+    # Either way the line is marked and is no result.
+    rehearsal = os.environ.get("RRT_BENCH_REHEARSAL", "")
+    plumbing = rehearsal == "plumbing"
+    if not plumbing and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
-    # RRT_BENCH_REHEARSAL=1: every rank on GPU 0, gloo instead of RCCL -- exercises the multi-rank code path
-    # (shards, reduce, max-over-ranks timing) on a one-GPU box; the line it prints is marked and is no result
-    rehearsal = os.environ.get("RRT_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
+    dev = "cpu" if plumbing else "cuda"
+    if not plumbing:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -138,47 +240,66 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import make_c5_assets
 
-        if local_rank == 0:
+        if local_rank == 0 and (rank == 0 or not rehearsal):
             make_c5_assets.main()  # deterministic generator; the 25 MB of PLY are not committed
         if world > 1:
             dist.barrier()
     flat = config.load_scene(os.path.join(ROOT, scene_file))
-    be = api.Backend(local_rank)
-    scene = api.Scene(flat)
-    stream = torch.cuda.current_stream()
-    be.set_stream(stream.cuda_stream)
 
     side = args.spp_side or default_side
-    xs, ys = D.weak_scaling_strata(side, side, world)
+    if args.scaling == "weak":
+        xs, ys = D.weak_scaling_strata(side, side, world)
+    else:
+        xs, ys = side, side
     rc = config.stratified_config(width, height, xs, ys)
     lo, hi = D.shard_range(rc.spp, rank, world)
-    pipeline = {"auto": api.PIPELINE_AUTO, "fused": api.PIPELINE_FUSED, "wavefront": api.PIPELINE_WAVEFRONT}[args.pipeline]
-    precision = api.PRECISION_F64 if args.precision == "f64" else api.PRECISION_F32
-    desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline, precision=precision)
-    # what AUTO resolves to (include/rrt.h): the tree for more than 160 primitives, the wavefront pipeline above 800
+    if hi <= lo:
+        raise SystemExit("rank %d of %d has no sample index of %d spp" % (rank, world, rc.spp))
+
     use_tree = flat.n_prims > 160
     wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and flat.n_prims > 800 and args.precision == "f32")
-    post = rc.post_desc()
-    acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32, device="cuda")
-    img = torch.zeros((rc.height, rc.width, 3), dtype=torch.uint8, device="cuda")
+    if plumbing:
+        acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32)
 
-    def step():
-        acc.zero_()
-        _, st = be.render_accumulate(scene, desc, acc)
-        if rehearsal and world > 1:
-            host = acc.cpu()
-            D.reduce_sum(host, dst=0)
-            acc.copy_(host)
-        else:
+        def step():
+            acc.fill_(float(hi - lo))
             D.reduce_sum(acc, dst=0)
-        if rank == 0:
-            be.postprocess(acc, rc.spp, post, out=img)
-        return st
+            if rank == 0 and not bool((acc == float(rc.spp)).all()):
+                raise SystemExit("the shards do not add up to %d samples per pixel" % rc.spp)
+            n = (hi - lo) * rc.width * rc.height
+            return {"samples": n, "rays": n, "kernel_ms": 0.0, "nonfinite": 0, "node_tests": 0, "prim_tests": 0,
+                    "bounces": [0] * 5}
+    else:
+        from rustraytracer_amd import api
+
+        be = api.Backend(local_rank)
+        scene = api.Scene(flat)
+        be.set_stream(torch.cuda.current_stream().cuda_stream)
+        pipeline = {"auto": api.PIPELINE_AUTO, "fused": api.PIPELINE_FUSED, "wavefront": api.PIPELINE_WAVEFRONT}[args.pipeline]
+        precision = api.PRECISION_F64 if args.precision == "f64" else api.PRECISION_F32
+        desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline, precision=precision)
+        post = rc.post_desc()
+        acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32, device="cuda")
+        img = torch.zeros((rc.height, rc.width, 3), dtype=torch.uint8, device="cuda")
+
+        def step():
+            acc.zero_()
+            _, st = be.render_accumulate(scene, desc, acc)
+            if rehearsal and world > 1:
+                host = acc.cpu()
+                D.reduce_sum(host, dst=0)
+                acc.copy_(host)
+            else:
+                D.reduce_sum(acc, dst=0)
+            if rank == 0:
+                be.postprocess(acc, rc.spp, post, out=img)
+            return st
 
     def fence():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not plumbing:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -194,94 +315,103 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
-    cdev = "cpu" if rehearsal else "cuda"
-    counts = torch.tensor([tot["samples"], tot["rays"]], dtype=torch.float64, device=cdev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    cdev = "cpu" if rehearsal else dev
+    counts = torch.tensor([tot["samples"], tot["rays"], 1.0], dtype=torch.float64, device=cdev)
+    tmax = torch.tensor([elapsed, tot["kernel_ms"]], dtype=torch.float64, device=cdev)
     if dist is not None:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-    all_samples, all_rays = float(counts[0].item()), float(counts[1].item())
+    elapsed = float(tmax[0].item())
+    all_samples, all_rays, ranks_seen = float(counts[0].item()), float(counts[1].item()), int(round(float(counts[2].item())))
 
     if rank == 0:
         fpr = scene_flops(flat)[0]
         flops = algorithmic_flops(tot, flat)  # rank 0's launches
+        executed = algorithmic_flops(tot, flat, EXECUTED_FLOPS_PER_PRIM_TEST)
         kernel_s = tot["kernel_ms"] / 1e3
         achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
         peak = PEAK_FP32_VALU_TFLOPS if args.precision == "f32" else PEAK_FP64_VALU_TFLOPS
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and args.workload == "cornell" and not wavefront:
-            try:
-                with open(tpath) as f:
-                    traffic = json.load(f).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = measured_traffic(args.workload, wavefront, args.precision)
         out = {
-            "metric": "Msamples/s (whole node), %s MCPT" % {"cornell": "Cornell Box 500x500", "smallpt": "smallpt 1024x768",
-                                                             "cornell_cube": "Cornell Box + test.ply 1024x1024",
-                                                             "mesh_1m": "1M-triangle mesh scene 3840x2160"}[args.workload],
+            "metric": "Msamples/s (whole node), %s MCPT" % METRIC_NAMES[args.workload],
             "value": all_samples / elapsed / 1e6,
             "unit": "Msamples/s",
             "mrays_per_s": all_rays / elapsed / 1e6,
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic (scenes of the reference configs; Cornell PLY meshes reconstructed from the canonical "
                     "measurements because the reference ships LFS stubs; the 1M-triangle meshes are generated)",
             "config": {
-                "workload": "%s, %dx%d, stratified %dx%d = %d spp in total, %d sample indices per GPU, MCPT "
-                            "min_depth 2 / max_depth 6" % (scene_file, width, height, xs, ys, rc.spp, hi - lo),
+                "workload": "%s, %dx%d, stratified %dx%d = %d spp in total, sample indices [%d, %d) of every pixel on "
+                            "rank 0 (%d per GPU), MCPT min_depth 2 / max_depth 6"
+                            % (scene_file, width, height, xs, ys, rc.spp, lo, hi, hi - lo),
                 "pipeline": "wavefront (SoA ray/hit queues in HBM, ballot/rank compaction)" if wavefront
                 else "fused (register-resident paths, lane regeneration)",
                 "closest_hit": "GPU-built LBVH (4-wide quantised nodes)" if use_tree else "linear scan (wave-uniform)",
                 "reduce": "RCCL sum-reduce of %.1f MB fp32 accumulators to rank 0" % (D.message_bytes(width, height) / 1e6)
                 if world > 1 else "none",
                 "samples_per_step": int(all_samples / args.steps),
-                "rays_per_sample": all_rays / all_samples,
+                "rays_per_sample": all_rays / max(all_samples, 1),
                 "nonfinite_samples": tot["nonfinite"],
             },
             "roofline": {
                 "bound": "valu_fp32" if args.precision == "f32" else "valu_fp64",
                 "kernel": ("wf_closest_hit_tree + wf_shade" if use_tree else "wf_shade<scan>") if wavefront
-                else "render_fused<float>",
+                else "render_fused<%s>" % ("float" if args.precision == "f32" else "double"),
                 "achieved": achieved,
                 "peak": peak,
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
+                "flops_counted_as": "the reference's arithmetic per primitive test (Moller-Trumbore 51, Lagae-Dutre 52, sphere 21, "
+                                    "plane 14), shading and ray generation: algorithmic work over peak, not hardware busy time",
                 "algorithmic_flops_per_launch": flops / args.steps,
+                "executed_flops_per_launch": executed / args.steps,
+                "executed_tflops": executed / kernel_s / 1e12 if kernel_s > 0 else 0.0,
+                "executed_note": "the kernels' own plane-form tests need about two thirds of the reference's operations per "
+                                 "primitive; executed_tflops / peak is the share of FP32 issue slots doing that arithmetic",
                 "flops_per_ray_scene": fpr,
                 "avg_launch_ms": tot["kernel_ms"] / args.steps,
             },
         }
         if rehearsal:
-            out["rehearsal"] = "all ranks on GPU 0, gloo: not a measurement"
+            out["rehearsal"] = ("plumbing only: no GPU, nothing rendered, not a measurement" if plumbing
+                                else "all ranks on GPU 0, gloo: not a measurement")
         if use_tree:
             out["config"]["node_tests_per_ray"] = tot["node_tests"] / max(tot["rays"], 1)
             out["config"]["prim_tests_per_ray"] = tot["prim_tests"] / max(tot["rays"], 1)
             # every traversal step fetches one 64-byte record (wide node or leaf primitive) per lane: the tree
             # kernel is bound by how fast the memory system serves such divergent gathers (L2 + HBM), not by flops
             steps = tot["node_tests"] + tot["prim_tests"]
-            out["roofline"]["tree_records_per_s"] = steps / kernel_s
-            out["roofline"]["tree_record_traffic_GBps"] = steps * 64 / kernel_s / 1e9
-            out["roofline"]["tree_note"] = ("64 B per traversal step; a fully divergent gather beyond L2 runs at 55-64 G records/s "
-                                            "on this GPU (tools/ubench/gather_rate.hip); PMC: L2 hit rate 0.58, 3.3 TB/s HBM-side")
-        if wavefront:
+            if kernel_s > 0:
+                out["roofline"]["tree_records_per_s"] = steps / kernel_s
+                out["roofline"]["tree_record_traffic_GBps"] = steps * 64 / kernel_s / 1e9
+        if wavefront and kernel_s > 0:
             out["roofline"]["queue_traffic_algorithmic_GBps"] = tot["rays"] * QUEUE_BYTES_PER_RAY / kernel_s / 1e9
-        if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 16)
+        if world == 1 and not args.no_cpu_baseline and not plumbing:
             cw, ch, cs = cpu_side if isinstance(cpu_side, tuple) else (width, height, cpu_side)
-            out["cpu_baseline"] = cpu_baseline(flat, args.workload, cw, ch, cs, threads)
+            out["cpu_baseline"] = cpu_baseline(flat, args.workload, cw, ch, cs, usable_cpus())
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))  # before any import of torch, before any GPU call
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -27,22 +27,38 @@ def test_single_gpu_line():
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "Msamples/s"
     assert d["config"]["samples_per_step"] == 500 * 500 * 64 and d["vs_baseline"] is None and d["dtype"] == "f32"
     rf, cb = d["roofline"], d["cpu_baseline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(rf) and 0 < rf["frac"] < 1
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"} <= set(rf) and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and d["value"] > 20 * cb["value"]
 
 
 def test_two_rank_rehearsal():
+    """`python bench.py --gpus 2` with no launcher in front: the script starts its two ranks itself (fresh children,
+    before any GPU call).  Strong scaling: ONE 64-spp image, 32 sample indices per rank."""
+    env = dict(os.environ, RRT_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--spp-side", "8", "--workload", "smallpt"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "strong" and "rehearsal" in d
+    assert d["config"]["samples_per_step"] == 1024 * 768 * 64  # the two ranks' 32 sample indices of every pixel
+    assert "cpu_baseline" not in d  # timed on rank 0 at N = 1 only
+
+
+def test_two_rank_rehearsal_weak_under_a_launcher():
+    """The way the driver starts N > 1: torch.distributed.run in front.  Weak scaling: 64 sample indices per rank."""
     env = dict(os.environ, RRT_BENCH_REHEARSAL="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
-                        "--warmup", "1", "--spp-side", "8", "--workload", "smallpt"],
+                        "--warmup", "1", "--spp-side", "8", "--workload", "smallpt", "--scaling", "weak"],
                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "rehearsal" in d
-    assert d["config"]["samples_per_step"] == 2 * 1024 * 768 * 64  # both ranks' 64 sample indices of every pixel
-    assert "cpu_baseline" not in d  # timed on rank 0 at N = 1 only
+    assert d["config"]["samples_per_step"] == 2 * 1024 * 768 * 64
 
 
 RCCL_PROBE = r'''
