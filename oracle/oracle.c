@@ -539,6 +539,12 @@ static int sampler_start_next_sample(sampler_t* s) {
     return 0;
 }
 
+/* Positions a freshly started pixel on sample index `index` (the head of a sample-index shard). */
+static void sampler_seek(sampler_t* s, size_t index) {
+    s->current_sample = index;
+    if (s->device_numbers) dev_start_sample(s);
+}
+
 /* ----------------------------------------------------------- material.rs */
 static const double ORACLE_PI = 3.14159265358979323846264338327950288;
 static const double FRAC_1_PI = 0.318309886183790671537767526745028724;
@@ -748,11 +754,22 @@ static void render_tile(render_job* job, size_t tile_index, trace_counters* cnt,
     sampler.device_numbers = job->device_numbers;
     sampler.seed_lo = (uint32_t)rd->seed;
     sampler.seed_hi = (uint32_t)(rd->seed >> 32);
+    /* The reference's loop (src/renderer.rs:118-127) runs over every sample of the pixel: spp for the stratified
+     * sampler, spp + 1 for the random one (src/sampler.rs:48-55).  A device backend shards that loop by sample index
+     * (rrt_render_desc.sample_begin / sample_end); the same range is honoured here so that a shard can be checked
+     * on its own.  sample_end == 0 means "all".  With the device's numbers every sample's draws depend on
+     * (seed, pixel, sample index) only, so the shards of a pixel add up to its full loop exactly. */
+    const uint64_t s_total = (uint64_t)rd->spp + (rd->sampler_type == RRT_SAMPLER_RANDOM ? 1u : 0u);
+    const uint64_t s_end = rd->sample_end && rd->sample_end < s_total ? rd->sample_end : s_total;
+    const uint64_t s_begin = rd->sample_begin;
     for (size_t y = y_start; y < y_end; ++y) {
         for (size_t x = x_start; x < x_end; ++x) {
             sampler.pixel = (uint32_t)(y * rd->width + x);
             sampler_start_pixel(&sampler);
             v3 color = V(0, 0, 0);
+            double* out = job->rgb_sum + 3 * (y * rd->width + x);
+            if (s_begin >= s_end) { out[0] = out[1] = out[2] = 0.0; continue; }
+            sampler_seek(&sampler, (size_t)s_begin);
             for (;;) {
                 double u_offset, v_offset;
                 sampler_get_2d(&sampler, &u_offset, &v_offset);
@@ -761,9 +778,9 @@ static void render_tile(render_job* job, size_t tile_index, trace_counters* cnt,
                 ray_t ray = create_ray(&job->scene->camera, u, v);
                 color = vadd(color, trace(job->scene, &ray, &sampler, rd->min_depth, rd->max_depth, cnt));
                 (*samples)++;
+                if (sampler.current_sample + 1 >= s_end) break;
                 if (!sampler_start_next_sample(&sampler)) break;
             }
-            double* out = job->rgb_sum + 3 * (y * rd->width + x);
             out[0] = color.x; out[1] = color.y; out[2] = color.z;
         }
     }

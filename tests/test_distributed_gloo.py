@@ -1,4 +1,5 @@
-"""N > 1 path on CPU: sample-index sharding + sum-reduce of the accumulators, world_size 2, gloo."""
+"""N > 1 path on CPU (gloo): every rank renders only its sample-index shard, the accumulators are sum-reduced to
+rank 0, and the result must be the unsharded render."""
 import os
 import socket
 import subprocess
@@ -39,34 +40,49 @@ WORKER = textwrap.dedent("""
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     flat = config.load_scene(os.path.join(%r, "configs", "cornell_box", "scene.toml"))
-    rc = config.stratified_config(16, 16, 4, 4, seed=rank + 1)
-    lo, hi = D.shard_range(rc.spp, rank, world)
-    # each rank contributes (its share of the samples) x (a render of the scene): what matters here is
-    # that the reduce adds the two accumulators element-wise on rank 0 and leaves the shard plan intact
-    rgb, st = O.render_accumulate(flat, rc.render_desc())
-    mine = torch.from_numpy((rgb * (hi - lo) / rc.spp).astype(np.float32))
-    keep = mine.clone()
-    D.reduce_sum(mine, dst=0)
-    gathered = [torch.zeros_like(keep) for _ in range(world)]
-    dist.all_gather(gathered, keep)
-    if rank == 0:
-        expect = sum(gathered)
-        assert torch.allclose(mine, expect, rtol=1e-6), "reduce != sum of shards"
-        assert (hi - lo) * world == rc.spp
-        print("GLOO_OK", float(mine.mean()))
+    for name, rc in (("stratified", config.stratified_config(24, 20, 5, 3, seed=7)),
+                     ("random", config.random_config(24, 20, 9, seed=7))):
+        total = rc.samples_traced                       # spp, or spp + 1 for the random sampler
+        lo, hi = D.shard_range(total, rank, world)
+        # this rank traces ONLY its sample indices of every pixel, with the counter-based numbers of the device
+        # sampler (a sample's draws depend on seed, pixel and sample index alone, as on the GPUs)
+        mine, st = O.render_accumulate(flat, rc.render_desc(sample_begin=lo, sample_end=hi), n_threads=2, device_numbers=True)
+        assert st["samples"] == (hi - lo) * rc.width * rc.height, (st["samples"], lo, hi)
+        part = torch.from_numpy(mine.copy())
+        D.reduce_sum(part, dst=0)
+        counts = torch.tensor([float(st["samples"]), float(st["rays"])], dtype=torch.float64)
+        dist.all_reduce(counts)
+        if rank == 0:
+            whole, wst = O.render_accumulate(flat, rc.render_desc(), n_threads=2, device_numbers=True)
+            err = np.abs(part.numpy() - whole).max() / np.abs(whole).max()
+            assert err <= 1e-12, "%%s: sum of the shards differs from the unsharded render by %%g" %% (name, err)
+            assert whole.max() > 0
+            assert int(counts[0]) == wst["samples"] == total * rc.width * rc.height
+            assert int(counts[1]) == wst["rays"]
+            # a shard on its own is NOT the image: the test would pass trivially if every rank rendered everything
+            assert np.abs(mine - whole).max() > 0.1 * np.abs(whole).max()
+            print("GLOO_OK", name, world, err)
     dist.destroy_process_group()
 """)
 
 
-def test_two_rank_reduce_gloo(tmp_path):
+def run_workers(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % (ROOT, ROOT))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "GLOO_OK" in out.stdout
+    assert out.stdout.count("GLOO_OK") == 2
+
+
+def test_two_rank_shards_reduce_to_the_unsharded_render(tmp_path):
+    run_workers(tmp_path, 2)
+
+
+def test_three_rank_uneven_shards(tmp_path):
+    run_workers(tmp_path, 3)   # 15 and 10 sample indices over 3 ranks: 5/5/5 and 3/3/4
