@@ -67,7 +67,7 @@ typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_
 
 /* How closest-hit walks the primitives.  AUTO = wave-uniform linear scan for
  * scenes of up to 160 primitives (where it is the faster of the two), LBVH
- * (+ linear scan of the unbounded planes) otherwise. */
+ * (+ linear scan of the unbounded planes and of quads that are not planar) otherwise. */
 typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2 } rrt_accel;
 
 /* Which kernel organisation renders.  FUSED keeps a path in registers for

@@ -60,7 +60,7 @@ int main(void) {
             rd.width = W; rd.height = H;
             rd.sampler_type = sampler ? RRT_SAMPLER_STRATIFIED : RRT_SAMPLER_RANDOM;
             rd.spp = 12; rd.x_strata = 4; rd.y_strata = 3;
-            rd.min_depth = 1; rd.max_depth = 7; rd.seed = 5; rd.sample_end = rd.spp;
+            rd.min_depth = 1; rd.max_depth = 7; rd.seed = 5; rd.sample_end = 0; /* every sample of the pixel loop */
             rrt_stats st;
             memset(rgb, 0, sizeof(double) * W * H * 3);
             int rc = mode == 0 ? oracle_render_accumulate(&scene, &rd, rgb, &st, 3)

@@ -112,6 +112,7 @@ void prepare_prim(const rrt_prim& p, rrt::PrimRec<double>& rec, rrt::ShadeRec<do
         dual(e23, e21, n2, v2, &rec.f[12]);
         dual(e21, e23, n2, v2, &rec.f[16]);
         rec.f[20] = n2.x; rec.f[21] = n2.y; rec.f[22] = n2.z;
+        rec.f[23] = dot(n2, v2);
     }
     // the normal the reference reports for a hit: normalize((v1-v0) x (v2-v0))
     // (src/shapes/triangle.rs:78-80, quadrilateral.rs:180-182, mesh.rs:49-51,70-72)
@@ -134,7 +135,7 @@ void prepare_material(const rrt_material& m, rrt::MatRec<double>& out) {
 template <typename R>
 rrt::PrimRec<R> narrow(const rrt::PrimRec<double>& a) {
     rrt::PrimRec<R> o;
-    for (int i = 0; i < 23; ++i) o.f[i] = (R)a.f[i];
+    for (int i = 0; i < 24; ++i) o.f[i] = (R)a.f[i];
     o.type = a.type;
     return o;
 }
@@ -334,6 +335,22 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
             }
         }
     };
+    // Which primitives stay out of the tree and are scanned beside it: planes (unbounded), and quads that are bent.
+    // A bent quad reports its hit on the plane of (v0, v1, v3) while the corner at v2 is judged on the plane of
+    // (v2, v3, v1) (src/shapes/quadrilateral.rs:90-114); for a grazing ray the reported point can lie well outside the
+    // box of the four corners, so no box makes the tree return what the scan returns.  Bent by up to 1e-6 of its
+    // extent (corners rounded to f32 in a PLY file) a quad stays in the tree: the padding of its box covers rays down
+    // to half a degree of grazing.
+    auto outside_tree = [](const rrt_prim& p) {
+        if (p.type == RRT_PRIM_PLANE) return true;
+        if (p.type != RRT_PRIM_QUAD) return false;
+        D3 v0 = d3(p.v), v1 = d3(p.v + 3), v2 = d3(p.v + 6), v3 = d3(p.v + 9);
+        D3 n = cross(v1 - v0, v3 - v0);
+        double len = std::sqrt(dot(n, n));
+        double ext = std::sqrt(std::fmax(std::fmax(dot(v1 - v0, v1 - v0), dot(v2 - v0, v2 - v0)), dot(v3 - v0, v3 - v0)));
+        if (!(len > 0.0) || !(ext > 0.0)) return false;  // degenerate: every ray misses it
+        return std::fabs(dot(n, v2 - v0)) / len > 1e-6 * ext;
+    };
     // Largest coordinate magnitude a traversal works with: the scene's bounded primitives and the
     // camera (every other ray starts on a surface).  The slab tests are exact up to a few f32 ulps
     // of the distance between ray origin and box, and the f32 primitive tests accept points a few
@@ -341,14 +358,14 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
     double scale = 0;
     for (int k = 0; k < 3; ++k) scale = std::fmax(scale, std::fabs(sc->camera.origin[k]));
     for (const rrt_prim& p : sc->prims) {
-        if (p.type == RRT_PRIM_PLANE) continue;
+        if (outside_tree(p)) continue;
         double blo[3], bhi[3];
         bounds(p, blo, bhi);
         for (int k = 0; k < 3; ++k) scale = std::fmax(scale, std::fmax(std::fabs(blo[k]), std::fabs(bhi[k])));
     }
     for (size_t g = 0; g < sc->prims.size(); ++g) {
         const rrt_prim& p = sc->prims[g];
-        if (p.type == RRT_PRIM_PLANE) {
+        if (outside_tree(p)) {
             unbounded.push_back((int32_t)g);
             continue;
         }

@@ -216,7 +216,7 @@ RRT_DEV void leaf_test(const SceneView<R>& sv, const LeafRec<R>* leaf, V3<R> o, 
     if (ok) hit_consider(acc, t, g, type != PRIM_TRIANGLE);
 }
 
-// The primitives kept out of the tree (unbounded planes), scanned wave-uniformly.
+// The primitives kept out of the tree (unbounded planes, bent quads), scanned wave-uniformly.
 template <typename R>
 RRT_DEV void scan_beside_tree(const SceneView<R>& sv, V3<R> o, V3<R> d, HitAcc<R>& acc, HitCounters& hc) {
     const PrimRec<R> RRT_CONSTANT* prims = as_constant(sv.prims);

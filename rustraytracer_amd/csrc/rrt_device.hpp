@@ -255,9 +255,9 @@ RRT_DEV V3<R> camera_dir(const SceneView<R>& sv, R s, R t) {
 //   beta  = d . ((o-v0) x e01) / det = coefficient of (P - v0) on e03
 // with P = o + t d.  The coefficients are affine in P, so they are two dot
 // products with vectors prepared on the host.  Same accept/reject conditions,
-// about half the arithmetic.  The second corner test of a quad is evaluated
-// at the same P (the reference intersects the second triangle's own plane,
-// which is the same plane for the planar quads its loader admits).
+// about half the arithmetic.  The second corner test of a general quad is
+// evaluated at the ray's intersection with the second triangle's own plane,
+// as in the reference; for a parallelogram it folds into the first.
 //
 // The chain of early returns becomes ONE comparison: every condition is
 // written as "term >= 0" (x >= c <=> x - c >= 0 holds exactly in floating
@@ -304,9 +304,17 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
             return min3(h, t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
         }
         if (TYPE == PRIM_QUAD) {
-            R a2 = ((f[12] * P.x + f[13] * P.y) + f[14] * P.z) + f[15];
-            R b2 = ((f[16] * P.x + f[17] * P.y) + f[18] * P.z) + f[19];
+            // The corner at v2 (src/shapes/quadrilateral.rs:90-111): the reference intersects the ray with the
+            // plane of the triangle (v2, v3, v1) ITSELF and takes the coefficients of that point on e23 and
+            // e21.  For a planar quad it is the point P; the loader admits quads bent by up to 2.5 degrees
+            // (quadrilateral.rs:23-33) and a Quadrilateral object is not checked at all (quadrilateral.rs:204-216),
+            // and there the two points differ.  The distance stays the first plane's (quadrilateral.rs:114).
             R nd2 = f[20] * d.x + f[21] * d.y + f[22] * d.z;
+            R no2 = f[23] - ((f[20] * o.x + f[21] * o.y) + f[22] * o.z);
+            R t2 = no2 * Num<R>::rcp(nd2);
+            V3<R> P2 = mk<R>(o.x + t2 * d.x, o.y + t2 * d.y, o.z + t2 * d.z);
+            R a2 = ((f[12] * P2.x + f[13] * P2.y) + f[14] * P2.z) + f[15];
+            R b2 = ((f[16] * P2.x + f[17] * P2.y) + f[18] * P2.z) + f[19];
             R second = min3(a2, b2, Num<R>::abs(nd2) - Num<R>::eps());  // the (v2, v3, v1) corner
             R inside = fmax(R(1) - (a + b), second);                      // alpha + beta <= 1, or that corner
             R h = min3(min3(a, b, inside), det_ok, t - Num<R>::tmin());

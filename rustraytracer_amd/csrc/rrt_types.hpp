@@ -27,12 +27,13 @@ enum : int { MAT_EMISSIVE = 0, MAT_LAMBERTIAN = 1, MAT_PHONG = 2, MAT_REFLECTOR 
 //     general quad only, second corner v2:
 //     f[12..14] A2, f[15] cA2   alpha' on e23 = v3 - v2
 //     f[16..18] B2, f[19] cB2   beta'  on e21 = v1 - v2
-//     f[20..22] n2 = e23 x e21
+//     f[20..22] n2 = e23 x e21, f[23] n2 . v2: the plane of the triangle (v2, v3, v1), which the second
+//               corner test intersects on its own (it differs from the first plane when the quad is bent)
 //   sphere   f[0..2] centre, f[3] radius, f[4] radius^2
 //   plane    f[0..2] unit normal, f[3] normal . point
 template <typename R>
 struct PrimRec {
-    R f[23];
+    R f[24];
     int32_t type;
 };
 
@@ -135,7 +136,7 @@ struct SceneView {
     const WideNode* nodes;      // n_bvh_prims - 1 nodes, node 0 is the root
     const int32_t* bvh_prim;    // sorted slot -> scan-order primitive index
     const LeafRec<R>* leaves;   // n_bvh_prims, sorted-slot order
-    const int32_t* linear_prim; // primitives kept out of the tree (unbounded planes), scan order
+    const int32_t* linear_prim; // primitives kept out of the tree (unbounded planes, bent quads), scan order
     int32_t n_bvh_prims;
     int32_t n_linear_prims;
 };

@@ -114,3 +114,27 @@ def scene_intersect(prims, o, d):
         pid = np.where(ok, np.int32(p["prim_id"]), pid)
     t = np.where(oid >= 0, best_t, np.inf)
     return oid, pid, t
+
+
+def quad_margin(v, o, d):
+    """Distance of a ray from every decision the quad test takes (src/shapes/quadrilateral.rs:71-111): the smallest of
+    |alpha|, |beta|, |alpha + beta - 1| and, where the second corner is consulted, |alpha'|, |beta'|.  A ray with a
+    margin far above the rounding of the arithmetic gets the same verdict in any precision."""
+    v0, v1, v2, v3 = v[0:3], v[3:6], v[6:9], v[9:12]
+    e01, e03 = v1 - v0, v3 - v0
+    p = np.cross(d, e03)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / _dot(p, e01)
+        tv = o - v0
+        alpha = _dot(tv, p) * inv
+        beta = _dot(d, np.cross(tv, e01)) * inv
+        e23, e21 = v3 - v2, v1 - v2
+        pp = np.cross(d, e21)
+        invp = 1.0 / _dot(pp, e23)
+        tp = o - v2
+        ap = _dot(tp, pp) * invp
+        bp = _dot(d, np.cross(tp, e23)) * invp
+    m = np.minimum(np.minimum(np.abs(alpha), np.abs(beta)), np.abs(alpha + beta - 1.0))
+    second = (alpha >= 0) & (beta >= 0) & (alpha + beta > 1.0)
+    m = np.where(second, np.minimum(m, np.minimum(np.abs(ap), np.abs(bp))), m)
+    return np.where(np.isfinite(m), m, 0.0)

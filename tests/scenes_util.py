@@ -91,3 +91,62 @@ def secondary_rays(flat, O, n, seed):
     o_all = np.concatenate([np.broadcast_to(cam["origin"], d.shape), o2])
     d_all = np.concatenate([d, d2])
     return np.ascontiguousarray(o_all), np.ascontiguousarray(d_all)
+
+
+# ---- quads that are not planar -------------------------------------------------------------------
+# The mesh loader admits quads whose two triangle normals differ by up to | |cos| - 1 | < 1e-3, about 2.5 degrees
+# (src/shapes/quadrilateral.rs:23-33), and a [[objects]] Quadrilateral is not checked at all
+# (quadrilateral.rs:204-216).  The second corner test then runs on another plane than the first
+# (quadrilateral.rs:90-111), which is what these scenes are for.
+BENT_LIFT_MESH = 0.028   # cos = 1 / (1 + h^2) = 0.99922
+BENT_LIFT_FREE = 0.3
+
+
+def bent_quad(x0, y0, lift, z=0.0, size=1.0):
+    """Unit-square quad (v0..v3 counter-clockwise seen from +z) with its corner v2 lifted out of the plane."""
+    return np.array([[x0, y0, z], [x0 + size, y0, z], [x0 + size, y0 + size, z + lift], [x0, y0 + size, z]], dtype=np.float64)
+
+
+def bent_quad_scenes():
+    """-> {name: (FlatScene, list of quad vertex arrays)}: a 2x2 'mesh' of loader-admissible bent quads over a triangle
+    backdrop, and one freely bent Quadrilateral object in front of a sphere and a triangle."""
+    mats = [(_abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)] * 3
+    mesh = [bent_quad(x, y, BENT_LIFT_MESH * s) for (x, y, s) in ((-1, -1, 1), (0, -1, -1), (-1, 0, -1), (0, 0, 1))]
+    prims = [(3, 0, i, q) for i, q in enumerate(mesh)]
+    prims += [(2, 1, 0, [[-3, -3, -1], [3, -3, -1], [0, 3, -1]]), (2, 1, 1, [[-3, 3, -1.5], [3, 3, -1.5], [0, -3, -1.5]])]
+    free = [bent_quad(-0.5, -0.5, BENT_LIFT_FREE), bent_quad(-0.5, -0.5, -BENT_LIFT_FREE, z=-0.5)]
+    prims2 = [(3, 0, 0, free[0]), (0, 1, 0, [0.2, 0.2, -2.0, 1.0]), (3, 2, 0, free[1]),
+              (2, 1, 0, [[-3, -3, -3], [3, -3, -3], [0, 3, -3]])]
+    return {"mesh_bent": (make_scene(prims, mats, look_from=(0, 0, 4), look_at=(0, 0, 0), vfov=40.0), mesh),
+            "free_bent": (make_scene(prims2, mats, look_from=(0, 0, 4), look_at=(0, 0, 0), vfov=30.0), free)}
+
+
+def bent_quad_rays(quads, seed, per_target=6):
+    """Rays aimed at the places where the two planes of a bent quad disagree: points along the edges v2-v3 and v2-v1
+    (just inside and just outside), along the diagonal v1-v3, at the lifted corner, and random points of the quad;
+    from steep and from grazing directions on both sides."""
+    rng = np.random.default_rng(seed)
+    targets = []
+    for q in quads:
+        v0, v1, v2, v3 = q
+        centre = q.mean(axis=0)
+        for s in np.linspace(0.02, 0.98, 13):
+            for a, b in ((v2, v3), (v2, v1), (v1, v3)):
+                p = a + s * (b - a)
+                inward = centre - p
+                inward /= np.linalg.norm(inward) + 1e-300
+                for off in (-3e-2, -1e-3, 1e-3, 3e-2):
+                    targets.append(p + off * inward)
+        targets.append(v2 + 1e-3 * (centre - v2))
+        for _ in range(20):
+            a, b = rng.random(2)
+            targets.append(v0 + a * (v1 - v0) + b * (v3 - v0) + (a * b) * (v2 - v1 - v3 + v0))
+    targets = np.repeat(np.array(targets), per_target, axis=0)
+    n = len(targets)
+    # directions: polar angle from the quad's base plane normal (z), from steep to 2 degrees of grazing, both sides
+    elev = np.deg2rad(rng.choice([80.0, 45.0, 20.0, 8.0, 2.0], n)) * rng.choice([-1.0, 1.0], n)
+    azim = rng.uniform(0, 2 * np.pi, n)
+    d = -np.stack([np.cos(elev) * np.cos(azim), np.cos(elev) * np.sin(azim), np.sin(elev)], axis=1)
+    dist = rng.uniform(0.5, 3.0, n)
+    o = targets - d * dist[:, None]
+    return np.ascontiguousarray(o), np.ascontiguousarray(d / np.linalg.norm(d, axis=1, keepdims=True))
