@@ -36,7 +36,14 @@ def test_bent_quads_against_the_oracle(gpu, O, name):
         assert clear.sum() > 0.8 * len(o)
         assert np.array_equal(oid[clear], ref[0][clear]) and np.array_equal(pid[clear], ref[1][clear]), (name, accel)
         both = clear & hit
-        assert np.all(np.abs(t[both] - ref[2][both]) <= 1e-5 * np.abs(ref[2][both]))
+        # 1e-5 relative for rays that meet the surface at a fair angle; a ray that grazes it (down to 2 degrees here)
+        # divides the f32 rounding of n.o (coordinates of size |o|) by a small n.d: every surface here faces +-z
+        tol = 1e-5 * np.abs(ref[2]) + 5e-7 * np.linalg.norm(o, axis=1) / np.abs(d[:, 2])
+        assert np.all(np.abs(t[both] - ref[2][both]) <= tol[both])
+        steep = both & (np.abs(d[:, 2]) > 0.3)
+        # (an origin a few units away fixes the absolute error at a few f32 ulps of |o|, however short the ray)
+        assert steep.sum() > 100
+        assert np.all(np.abs(t[steep] - ref[2][steep]) <= 1e-5 * np.abs(ref[2][steep]) + 5e-7 * np.linalg.norm(o[steep], axis=1))
         assert (oid != ref[0]).sum() <= 0.02 * len(o)  # edge grazes only
 
 
