@@ -189,6 +189,20 @@ int rrt_trace_primary(rrt_backend* backend, const rrt_scene* scene, uint32_t pre
                       size_t n, const double* u, const double* v,
                       int32_t* object_id, int32_t* prim_id, double* t);
 
+/* rrt_intersect without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory at the time of the call (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  rrt_intersect allocates five staging buffers per call; this variant stages the rays and the
+ * results in a fixed array that lives in the library's device image (4 MiB per GPU the library runs on, held until
+ * the process ends), so it takes at most RRT_INTERSECT_STATIC_MAX_RAYS rays per call and fails with RRT_ERR_INVALID
+ * beyond that.  The scene must already be resident on the backend's device (and its LBVH built, if `accel` asks for
+ * the tree): one earlier rrt_intersect call with the same scene and accel does both; otherwise RRT_ERR_INVALID.
+ * Same arguments, results and kernels as rrt_intersect.  Every call on one GPU uses that GPU's one array: calls that
+ * overlap on a GPU (two host threads, two backends on the same device) race and must be serialised by the caller. */
+#define RRT_INTERSECT_STATIC_MAX_RAYS 65536
+int rrt_intersect_static(rrt_backend* backend, const rrt_scene* scene, uint32_t precision, uint32_t accel,
+                         size_t n, const double* origins, const double* dirs,
+                         int32_t* object_id, int32_t* prim_id, double* t);
+
 /* The pixel/sample loop of render (src/renderer.rs:101-128) with
  * MonteCarloPathTracer::trace (src/tracers/mcpt.rs:20-43) inside, for sample
  * indices [sample_begin, sample_end) of every pixel.  ADDS the radiance of the

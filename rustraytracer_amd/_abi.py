@@ -20,6 +20,7 @@ SAMPLER_RANDOM, SAMPLER_STRATIFIED = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH = 0, 1, 2
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
+INTERSECT_STATIC_MAX_RAYS = 65536
 
 # numpy views of the plain-data structs (bulk construction of large scenes)
 PRIM_DTYPE = np.dtype(
@@ -116,6 +117,10 @@ SIGNATURES = {
     "rrt_backend_destroy": (None, [C.c_void_p]),
     "rrt_backend_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rrt_intersect": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, _dp, _dp, _i32p, _i32p, _dp],
+    ),
+    "rrt_intersect_static": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_size_t, _dp, _dp, _i32p, _i32p, _dp],
     ),

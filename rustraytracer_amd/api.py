@@ -95,6 +95,11 @@ class Backend:
         """Scene::intersect for n rays -> (object_id, prim_id, t); misses give -1, -1, inf."""
         return self._closest(self._lib.rrt_intersect, scene, origins, dirs, precision, accel, 3)
 
+    def intersect_static(self, scene, origins, dirs, precision=PRECISION_F32, accel=ACCEL_AUTO):
+        """rrt_intersect_static: Scene::intersect for at most _abi.INTERSECT_STATIC_MAX_RAYS rays without any
+        device allocation (the scene must already be resident: call intersect once first)."""
+        return self._closest(self._lib.rrt_intersect_static, scene, origins, dirs, precision, accel, 3)
+
     def trace_primary(self, scene, u, v, precision=PRECISION_F32, accel=ACCEL_AUTO):
         """Camera::create_ray(u, v) + Scene::intersect."""
         return self._closest(self._lib.rrt_trace_primary, scene, u, v, precision, accel, 1)

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -20,9 +21,27 @@
 #include "rrt_types.hpp"
 #include "rrt_wavefront.hpp"
 
+// Staging memory of rrt_intersect_static: the rays of one call and their results.  One copy per GPU the
+// library runs on, held until the process ends.  In host code the NAME of a __device__ array is a host-side stand-in,
+// not a device address: every use below goes through the pointer hipGetSymbolAddress returned for the device.
+struct StaticRays {
+    double origins[3 * RRT_INTERSECT_STATIC_MAX_RAYS];
+    double dirs[3 * RRT_INTERSECT_STATIC_MAX_RAYS];
+    double t[RRT_INTERSECT_STATIC_MAX_RAYS];
+    int32_t object_id[RRT_INTERSECT_STATIC_MAX_RAYS];
+    int32_t prim_id[RRT_INTERSECT_STATIC_MAX_RAYS];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(StaticRays)];
+
 namespace {
 
 thread_local std::string g_last_error;
+
+// Device address of `scratch` on each GPU (every GPU holds its own copy at its own address), resolved once per
+// device by rrt_backend_create with that device current.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+StaticRays* g_scratch_ptr[kMaxDevices] = {};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -763,7 +782,16 @@ int rrt_backend_create(const char* name, int device_id, rrt_backend** out) {
     if (!be) return fail(RRT_ERR_NOMEM, "out of host memory");
     be->device = device_id;
     be->n_cu = prop.multiProcessorCount;
-    hipError_t e = hipEventCreate(&be->ev0);
+    hipError_t e = hipSuccess;
+    if (device_id < kMaxDevices) {  // (the device is current: hipSetDevice above)
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[device_id]) {
+            void* ptr = nullptr;
+            e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (e == hipSuccess) g_scratch_ptr[device_id] = (StaticRays*)ptr;
+        }
+    }
+    if (e == hipSuccess) e = hipEventCreate(&be->ev0);
     if (e == hipSuccess) e = hipEventCreate(&be->ev1);
     if (e == hipSuccess) e = hipMalloc((void**)&be->d_counters, sizeof(unsigned long long) * (rrt::COUNTER_COUNT + 1));
     if (e != hipSuccess) {
@@ -798,6 +826,54 @@ int rrt_intersect(rrt_backend* be, const rrt_scene* scene, uint32_t precision, u
 int rrt_trace_primary(rrt_backend* be, const rrt_scene* scene, uint32_t precision, uint32_t accel, size_t n,
                       const double* u, const double* v, int32_t* object_id, int32_t* prim_id, double* t) {
     return closest_hit_call(be, scene, precision, accel, true, n, u, v, object_id, prim_id, t);
+}
+
+int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t precision, uint32_t accel, size_t n,
+                         const double* origins, const double* dirs, int32_t* object_id, int32_t* prim_id, double* t) {
+    int rc = check_backend(be);
+    if (rc != RRT_OK) return rc;
+    if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
+    if (precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", precision);
+    if (accel > RRT_ACCEL_LBVH) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
+    if (n > (size_t)RRT_INTERSECT_STATIC_MAX_RAYS)
+        return fail(RRT_ERR_INVALID, "rrt_intersect_static takes at most %d rays per call, got %zu (split the batch, or use rrt_intersect)",
+                    RRT_INTERSECT_STATIC_MAX_RAYS, n);
+    if (n == 0) return RRT_OK;
+    if (!origins || !dirs || !object_id || !prim_id || !t) return fail(RRT_ERR_INVALID, "NULL array argument");
+    if (scene->prims.empty()) {
+        for (size_t i = 0; i < n; ++i) {
+            object_id[i] = -1;
+            prim_id[i] = -1;
+            t[i] = INFINITY;
+        }
+        return RRT_OK;
+    }
+    // nothing may be allocated here: the scene's tables (and its tree, if this query walks one) must already be on
+    // the device, which any earlier rrt_intersect / rrt_trace_primary / rrt_render_accumulate call of the same kind does
+    auto it = scene->dev.find(be->device);
+    if (it == scene->dev.end())
+        return fail(RRT_ERR_INVALID, "rrt_intersect_static: the scene is not resident on device %d yet; make one "
+                                     "rrt_intersect call with the same scene and accel first", be->device);
+    DeviceScene* ds = it->second;
+    const bool use_bvh = accel == RRT_ACCEL_LBVH || (accel == RRT_ACCEL_AUTO && scene->prims.size() > kAutoBvhThreshold);
+    if (use_bvh && !ds->has_bvh)
+        return fail(RRT_ERR_INVALID, "rrt_intersect_static: the scene's LBVH is not built on device %d yet; make one "
+                                     "rrt_intersect call with the same scene and accel first", be->device);
+    StaticRays* sp = be->device < kMaxDevices ? g_scratch_ptr[be->device] : nullptr;
+    if (!sp) return fail(RRT_ERR_UNSUPPORTED, "no static scratch on device %d", be->device);
+    // every byte a kernel reads (3n + 3n doubles) is written here first and every result the caller gets was
+    // written by this call's kernel, so what an earlier call left in the array never shows
+    HIP_TRY(hipMemcpyAsync(sp->origins, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice, be->stream));
+    HIP_TRY(hipMemcpyAsync(sp->dirs, dirs, n * 3 * sizeof(double), hipMemcpyHostToDevice, be->stream));
+    if (precision == RRT_PRECISION_F64)
+        HIP_TRY(rrt::launch_intersect(ds->v64, use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
+    else
+        HIP_TRY(rrt::launch_intersect(ds->v32, use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
+    HIP_TRY(hipMemcpyAsync(object_id, sp->object_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipMemcpyAsync(prim_id, sp->prim_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipMemcpyAsync(t, sp->t, n * sizeof(double), hipMemcpyDeviceToHost, be->stream));
+    HIP_TRY(hipStreamSynchronize(be->stream));
+    return RRT_OK;
 }
 
 int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_render_desc* desc,
