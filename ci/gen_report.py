@@ -8,7 +8,13 @@ wall-clock the whole invocation (ci/gen_report.py:188-201), keep its log, and li
 "<task>@<sampler> Sampler x <spp>spp@<W> x <H>" and time cost in report.html.  report.json adds the
 renderer's own counters (samples, rays, kernel time) when the executable writes them (--stats-json).
 
-    python ci/gen_report.py --executable rustraytracer_amd/host/rrt --config ci/report_configs.yml --output-dir report
+    python ci/gen_report.py --bin rustraytracer_amd/host/rrt --config ci/report_configs.yml --output_dir report
+
+Takes the reference harness's command line unchanged (ci/gen_report.py:250-258): --bin, --config, --output_dir, --id,
+--upload, --no_compress.  Without --no_compress every PNG is also converted to a JPEG, which the report then shows
+(ci/gen_report.py:203-211); --id is recorded in report.json; --upload is accepted and nothing is uploaded (the
+reference posts to imgur and a storage bucket; this harness has no network side).  --executable and --output-dir are
+this harness's own spellings of --bin and --output_dir.
 """
 import argparse
 import html
@@ -35,7 +41,15 @@ def git_head():
         return "unknown", ""
 
 
-def run_task(executable, scene_config, render_config, out_dir, extra_args):
+def convert_png_to_jpg(png_path, jpg_path):
+    """ci/gen_report.py:60-66 of the reference: RGB JPEG next to the PNG."""
+    from PIL import Image
+
+    with Image.open(png_path) as im:
+        im.convert("RGB").save(jpg_path, "JPEG", quality=95)
+
+
+def run_task(executable, scene_config, render_config, out_dir, extra_args, compress=False):
     stem = Path(render_config).stem
     image, log, stats = out_dir / f"{stem}.png", out_dir / f"{stem}.log", out_dir / f"{stem}.json"
     cmd = [str(executable), "--scene-config", str(scene_config), "--render-config", str(render_config), "--output",
@@ -56,6 +70,11 @@ def run_task(executable, scene_config, render_config, out_dir, extra_args):
         "sampler": rc["sampler"]["type"],
         "spp": rc["sampler"]["samples_per_pixel"],
     }
+    if proc.returncode == 0 and compress:
+        jpg = out_dir / f"{stem}.jpg"
+        convert_png_to_jpg(image, jpg)
+        entry["image"] = jpg.name
+        entry["png"] = image.name
     if proc.returncode == 0 and stats.exists():
         st = json.load(open(stats))
         entry["stats"] = st
@@ -84,14 +103,20 @@ def report_html(rep):
 
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    ap.add_argument("--executable", type=Path, required=True)
+    ap.add_argument("--bin", "--executable", dest="executable", type=Path, required=True)
     ap.add_argument("--config", type=Path, required=True)
-    ap.add_argument("--output-dir", type=Path, required=True)
+    ap.add_argument("--output_dir", "--output-dir", dest="output_dir", type=Path, required=True)
+    ap.add_argument("--id", type=str, default=None, help="report id, recorded in report.json")
+    ap.add_argument("--upload", action="store_true", help="accepted for compatibility; nothing is uploaded")
+    ap.add_argument("--no_compress", "--no-compress", dest="no_compress", action="store_true",
+                    help="keep the PNGs only (default: also write a JPEG per render and show that)")
     ap.add_argument("--extra-arg", action="append", default=[], help="passed through to the executable (repeatable)")
     args = ap.parse_args(argv)
     cfg = yaml.safe_load(open(args.config, "r", encoding="utf-8"))
     commit, desc = git_head()
-    rep = {"commit_hash": commit, "commit_description": desc, "tasks": []}
+    rep = {"id": args.id, "commit_hash": commit, "commit_description": desc, "tasks": []}
+    if args.upload:
+        print("--upload: this harness uploads nothing; images and logs stay under the output directory", flush=True)
     args.output_dir.mkdir(parents=True, exist_ok=True)
     failed = 0
     for task in cfg["tasks"]:
@@ -99,7 +124,7 @@ def main(argv=None):
         tdir.mkdir(parents=True, exist_ok=True)
         t = {"name": task["name"], "dir": task["name"], "scene_config": task["scene_config"], "renders": []}
         for rc in task["render_configs"]:
-            e = run_task(args.executable, Path(task["scene_config"]), Path(rc), tdir, args.extra_arg)
+            e = run_task(args.executable, Path(task["scene_config"]), Path(rc), tdir, args.extra_arg, compress=not args.no_compress)
             failed += e["returncode"] != 0
             t["renders"].append(e)
             print(f"{task['name']}: {rc}: exit {e['returncode']}, {e['time_cost_s']:.2f} s", flush=True)
