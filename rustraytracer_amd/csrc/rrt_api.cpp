@@ -258,13 +258,18 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view,
         }
         runs[runs.size() - 2] += 1;
     }
-    std::vector<rrt::PairRec<R>> pairs;  // parallelogram and triangle runs, two records side by side
+    // parallelogram and triangle runs, and sphere and plane runs of more than one, two records side by side
+    std::vector<rrt::PairRec<R>> pairs;
     for (size_t r = 0; r < runs.size(); r += 4) {
-        if (runs[r] != rrt::PRIM_PGRAM && runs[r] != rrt::PRIM_TRIANGLE) continue;
+        const bool round = runs[r] == rrt::PRIM_SPHERE || runs[r] == rrt::PRIM_PLANE;
+        if (runs[r] == rrt::PRIM_QUAD || (round && runs[r + 2] < 2)) continue;
         runs[r + 3] = (int32_t)pairs.size();
         for (int k = 0; k < runs[r + 2]; k += 2) {
             rrt::PairRec<R> pr;
             std::memset(&pr, 0, sizeof(pr));
+            // the pad of an odd run must be missed by every ray: n = 0 does that for the plane forms, a sphere
+            // needs radius^2 < 0 (with radius^2 = 0 a ray through its centre would hit it)
+            if (runs[r] == rrt::PRIM_SPHERE) pr.g[4][1] = (R)-1;
             for (int h = 0; h < 2 && k + h < runs[r + 2]; ++h)
                 for (int j = 0; j < 12; ++j) pr.g[j][h] = p[(size_t)runs[r + 1] + k + h].f[j];
             pairs.push_back(pr);

@@ -208,13 +208,19 @@ RRT_DEV R get_1d(Sampler& s, const RenderParams& rp, bool needed) {
     return Num<R>::uniform(next_bits(s));
 }
 
+// Sampler::get_2d (two_d) or get_1d (!two_d) in one piece of code (src/sampler.rs:135-151): a path tracer's lanes need one draw per bounce, of either
+// kind (pixel jitter and lobe samples are 2D, the dielectric's reflect-or-refract choice is 1D), and written as two
+// calls the stratum permutation -- most of the cost -- runs once per kind whenever a wave holds lanes of both.
+// A 2D draw takes two uniforms and ONE dimension.  a = the 1D value or the first component, b = the second (2D only).
 template <typename R>
-RRT_DEV void get_2d(Sampler& s, const RenderParams& rp, R& a, R& b) {
-    R j0 = Num<R>::uniform(next_bits(s));
-    R j1 = Num<R>::uniform(next_bits(s));
+RRT_DEV void get_draw(Sampler& s, const RenderParams& rp, bool two_d, R& a, R& b) {
+    const uint32_t base = s.key + s.ctr * 0x9E3779B9U;
+    R j0 = Num<R>::uniform(mix32(base));
+    R j1 = Num<R>::uniform(mix32(base + 0x9E3779B9U));  // the second uniform of a 2D draw (not consumed by a 1D one)
+    s.ctr += two_d ? 2u : 1u;
     if (s.dim < 4u) {
         uint32_t d = s.dim++;
-        uint32_t k = mix32(s.pixkey ^ ((2u * d + 2u) * 0x9E3779B9U));
+        uint32_t k = mix32(s.pixkey ^ ((2u * d + (two_d ? 2u : 1u)) * 0x9E3779B9U));
         uint32_t cell = permute(s.sample, rp.spp, rp.perm_mask, k);
         uint32_t xc, yc;  // x_cell = i % x_strata, y_cell = i / x_strata, src/sampler.rs:115-116
         if (rp.x_shift != 0xffffffffu) {
@@ -224,7 +230,7 @@ RRT_DEV void get_2d(Sampler& s, const RenderParams& rp, R& a, R& b) {
             yc = cell / rp.x_strata;
             xc = cell - yc * rp.x_strata;
         }
-        a = stratum_value(xc, j0, rp.x_strata, rp.inv_x_strata);
+        a = stratum_value(two_d ? xc : cell, j0, two_d ? rp.x_strata : rp.spp, two_d ? rp.inv_x_strata : rp.inv_spp);
         b = stratum_value(yc, j1, rp.y_strata, rp.inv_y_strata);
         return;
     }
@@ -435,6 +441,62 @@ RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int
     }
 }
 
+// Two planes or two spheres per step, the same way (a run of one keeps the scalar loop).  The arithmetic of each
+// record is prim_test_as's, operation by operation, so both give a primitive the same t and the same verdict.
+template <typename R, int TYPE>
+RRT_DEV void scan_run_pairs_round(const PairRec<R> RRT_CONSTANT* pairs, int first, int count, V3<R> o, V3<R> d,
+                                  R& best_t, int& best_g) {
+    typedef R R2 __attribute__((ext_vector_type(2)));
+    const int n_pairs = (count + 1) >> 1;
+    for (int k = 0; k < n_pairs; ++k) {
+        const R2 RRT_CONSTANT* f = reinterpret_cast<const R2 RRT_CONSTANT*>(pairs[k].g);
+        if (TYPE == PRIM_PLANE) {
+            R2 nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
+            R2 no = f[3] - ((f[0] * o.x + f[1] * o.y) + f[2] * o.z);
+            R2 rc;
+            rc.x = Num<R>::rcp(nd.x);
+            rc.y = Num<R>::rcp(nd.y);
+            R2 t = no * rc;
+            R2 tm = t - Num<R>::tmin();
+            const bool ok0 = min3(Num<R>::abs(nd.x) - Num<R>::eps(), (R)tm.x, headroom(best_t, (R)t.x)) >= R(0);
+            best_t = ok0 ? t.x : best_t;
+            best_g = ok0 ? first + 2 * k : best_g;
+            const bool ok1 = min3(Num<R>::abs(nd.y) - Num<R>::eps(), (R)tm.y, headroom(best_t, (R)t.y)) >= R(0);
+            best_t = ok1 ? t.y : best_t;
+            best_g = ok1 ? first + 2 * k + 1 : best_g;
+        } else {  // PRIM_SPHERE
+            R2 lx = f[0] - o.x, ly = f[1] - o.y, lz = f[2] - o.z;
+            R2 t_ca = lx * d.x + ly * d.y + lz * d.z;
+            R2 d2;
+            if (sizeof(R) == 4) {
+                R2 qx = lx - t_ca * d.x, qy = ly - t_ca * d.y, qz = lz - t_ca * d.z;
+                d2 = qx * qx + qy * qy + qz * qz;
+            } else {
+                d2 = (lx * lx + ly * ly + lz * lz) - t_ca * t_ca;
+            }
+            R2 x = f[4] - d2;
+            R2 t_hc;
+            t_hc.x = Num<R>::sqrt(x.x);
+            t_hc.y = Num<R>::sqrt(x.y);
+            R2 t0 = t_ca - t_hc, t1 = t_ca + t_hc;
+            R2 ts;
+            ts.x = t0.x < Num<R>::tmin() ? t1.x : t0.x;
+            ts.y = t0.y < Num<R>::tmin() ? t1.y : t0.y;
+            R2 tm = ts - Num<R>::tmin();
+            // (f32: d2 is a sum of squares, so min(x, d2) >= 0 exactly when x >= 0 and the d2 term of the
+            //  scalar test is dropped; f64 forms d2 as a difference and keeps it)
+            R in0 = sizeof(R) == 4 ? (R)x.x : fmin((R)x.x, (R)d2.x);
+            const bool ok0 = min3(in0, (R)tm.x, headroom(best_t, (R)ts.x)) >= R(0);
+            best_t = ok0 ? ts.x : best_t;
+            best_g = ok0 ? first + 2 * k : best_g;
+            R in1 = sizeof(R) == 4 ? (R)x.y : fmin((R)x.y, (R)d2.y);
+            const bool ok1 = min3(in1, (R)tm.y, headroom(best_t, (R)ts.y)) >= R(0);
+            best_t = ok1 ? ts.y : best_t;
+            best_g = ok1 ? first + 2 * k + 1 : best_g;
+        }
+    }
+}
+
 // Scene::intersect (src/scene.rs:35-47) as a scan over the primitive table in
 // the reference's order with a shrinking t_max.  The table index is uniform
 // across the wave, so records arrive through scalar loads.  The table is cut
@@ -448,8 +510,14 @@ RRT_DEV void scan_linear(const SceneView<R>& sv, V3<R> o, V3<R> d, R& best_t, in
     for (int r = 0; r < n_runs; ++r) {
         const int type = runs[4 * r], first = runs[4 * r + 1], count = runs[4 * r + 2];
         switch (type) {
-        case PRIM_SPHERE: scan_run<R, PRIM_SPHERE>(prims, first, count, o, d, best_t, best_g); break;
-        case PRIM_PLANE: scan_run<R, PRIM_PLANE>(prims, first, count, o, d, best_t, best_g); break;
+        case PRIM_SPHERE:
+            if (count > 1) scan_run_pairs_round<R, PRIM_SPHERE>(as_constant(sv.pairs) + runs[4 * r + 3], first, count, o, d, best_t, best_g);
+            else scan_run<R, PRIM_SPHERE>(prims, first, count, o, d, best_t, best_g);
+            break;
+        case PRIM_PLANE:
+            if (count > 1) scan_run_pairs_round<R, PRIM_PLANE>(as_constant(sv.pairs) + runs[4 * r + 3], first, count, o, d, best_t, best_g);
+            else scan_run<R, PRIM_PLANE>(prims, first, count, o, d, best_t, best_g);
+            break;
         case PRIM_TRIANGLE: scan_run_pairs<R, PRIM_TRIANGLE>(as_constant(sv.pairs) + runs[4 * r + 3], first, count, o, d, best_t, best_g); break;
         case PRIM_QUAD: scan_run<R, PRIM_QUAD>(prims, first, count, o, d, best_t, best_g); break;
         default: scan_run_pairs<R, PRIM_PGRAM>(as_constant(sv.pairs) + runs[4 * r + 3], first, count, o, d, best_t, best_g); break;

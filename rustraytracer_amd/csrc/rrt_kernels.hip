@@ -118,10 +118,8 @@ render_fused(SceneView<R> sv, RenderParams rp) {
         c_rays += (uint32_t)__popcll(__ballot(have_ray));
         int mode = MODE_NEW, counted = -1;
         bool bad = false;
-        V3<R> n = mk<R>(0, 0, 0);
-        MatRec<R> m;
-        m.r = m.g = m.b = m.param = R(0);
-        m.type = 0;
+        V3<R> n;     // surface of this trip's hit: set by process_hit, read by scatter, both only
+        MatRec<R> m;  // for lanes whose path goes on (mode != MODE_NEW)
         if (have_ray) {
             R t;
 #ifdef RRT_EXP_NOSCAN
@@ -220,9 +218,9 @@ render_fused(SceneView<R> sv, RenderParams rp) {
             s_next += 1;
         }
 
-        // -- C: one 2D draw for every lane that needs one
+        // -- C: one draw for every lane that needs one
         R u2 = R(0), v2 = R(0);
-        if (start || mode == MAT_LAMBERTIAN || mode == MAT_PHONG) get_2d<R>(path.smp, rp, u2, v2);
+        if (start || mode_draws(mode)) get_draw<R>(path.smp, rp, start || mode_draws_2d(mode), u2, v2);
 
         // -- D: the next ray
         have_ray = false;
@@ -249,7 +247,7 @@ render_fused(SceneView<R> sv, RenderParams rp) {
             path.depth = 0;
             have_ray = true;
         } else if (mode != MODE_NEW) {
-            have_ray = scatter<R>(rp, path, mode, n, m, u2, v2);
+            have_ray = scatter<R>(path, mode, n, m, u2, v2);
         }
     }
     if (!BVH) {
@@ -283,11 +281,12 @@ __global__ void __launch_bounds__(256) sampler_values_kernel(RenderParams rp, ui
     Sampler s;
     sampler_start(s, rp, pixel_key(rp.seed_lo, rp.seed_hi, pixel), rp.sample_begin + i);
     float* o = out + 8 * (size_t)i;
-    get_2d<float>(s, rp, o[0], o[1]);
-    o[2] = get_1d<float>(s, rp, true);
-    get_2d<float>(s, rp, o[3], o[4]);
-    o[5] = get_1d<float>(s, rp, true);
-    get_2d<float>(s, rp, o[6], o[7]);
+    float unused;
+    get_draw<float>(s, rp, true, o[0], o[1]);
+    o[2] = get_1d<float>(s, rp, true);  // the two forms of a 1D draw: get_1d (Russian roulette) ...
+    get_draw<float>(s, rp, true, o[3], o[4]);
+    get_draw<float>(s, rp, false, o[5], unused);  // ... and get_draw (the dielectric's number)
+    get_draw<float>(s, rp, true, o[6], o[7]);
 }
 
 // ------------------------------------------------------------------ material probe

@@ -189,9 +189,15 @@ RRT_DEV bool scatter_with(Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u
     return !(p.beta.x == R(0) && p.beta.y == R(0) && p.beta.z == R(0));
 }
 
+// The draw a path needs for its scatter step: the lobe samplers take a 2D sample, the dielectric one number
+// (src/material.rs:193-284 draws it before anything can fail), the mirror nothing.
+RRT_DEV bool mode_draws(int mode) { return mode == MAT_LAMBERTIAN || mode == MAT_PHONG || mode == MAT_DIELECTRIC; }
+RRT_DEV bool mode_draws_2d(int mode) { return mode != MAT_DIELECTRIC; }
+
+// (u, v) = the draw made for this mode with get_draw: the 2D lobe sample, or u = the dielectric's number
 template <typename R>
-RRT_DEV bool scatter(const RenderParams& rp, Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u, R v) {
-    return scatter_with<R>(p, mode, n, m, u, v, [&]() { return get_1d<R>(p.smp, rp, true); });
+RRT_DEV bool scatter(Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u, R v) {
+    return scatter_with<R>(p, mode, n, m, u, v, [&]() { return u; });
 }
 
 }  // namespace rrt

@@ -37,10 +37,10 @@ struct PrimRec {
     int32_t type;
 };
 
-// Two parallelograms (or two triangles) of one run side by side: g[k] = (f[k] of the first, f[k] of the second),
-// k = 0..11.  A wave-uniform pair lands in 24 SGPRs as 12 aligned pairs, which is the operand
+// Two records of one run side by side (parallelograms, triangles; planes and spheres in runs of more than one):
+// g[k] = (f[k] of the first, f[k] of the second), k = 0..11.  A wave-uniform pair lands in 24 SGPRs as 12 aligned pairs, which is the operand
 // shape of the packed FP32 instructions (v_pk_fma_f32 & co. do two FMAs per lane per issue
-// slot).  An odd run is padded with an all-zero record, which every ray rejects (n . d = 0).
+// slot).  An odd run is padded with a record that every ray rejects (all zero: n . d = 0; sphere: radius^2 = -1).
 template <typename R>
 struct PairRec {
     R g[12][2];

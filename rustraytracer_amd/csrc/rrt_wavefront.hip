@@ -368,9 +368,9 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
         }
     }
 
-    // -- one 2D draw for every lane that needs one, then the new ray
+    // -- one draw for every lane that needs one, then the new ray
     R u2 = R(0), v2 = R(0);
-    if (start || mode == MAT_LAMBERTIAN || mode == MAT_PHONG) get_2d<R>(path.smp, rp, u2, v2);
+    if (start || mode_draws(mode)) get_draw<R>(path.smp, rp, start || mode_draws_2d(mode), u2, v2);
     bool have_ray = false;
     if (start) {
         const uint32_t py = pixel / rp.width;
@@ -384,7 +384,7 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
         path.depth = 0;
         have_ray = true;
     } else if (mode != MODE_NEW) {
-        have_ray = scatter<R>(rp, path, mode, n, m, u2, v2);
+        have_ray = scatter<R>(path, mode, n, m, u2, v2);
     }
 
     // -- compaction
