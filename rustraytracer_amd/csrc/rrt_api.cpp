@@ -149,6 +149,14 @@ void prepare_material(const rrt_material& m, rrt::MatRec<double>& out) {
     if (m.type != RRT_MAT_EMISSIVE && m.type != RRT_MAT_LAMBERTIAN && m.type != RRT_MAT_PHONG) {
         out.r = out.g = out.b = 0.0;
     }
+    if (m.type == RRT_MAT_DIELECTRIC) {
+        // eta = eta_i / eta_t and 1 / eta^2 for a ray that enters (1 / ior) and one that leaves (ior), as the
+        // reference forms them (src/material.rs:193-284): the kernels select instead of dividing per bounce
+        const double eta_in = 1.0 * (1.0 / m.param), eta_out = m.param * (1.0 / 1.0);
+        out.r = eta_in;
+        out.g = 1.0 / (eta_in * eta_in);
+        out.b = 1.0 / (eta_out * eta_out);
+    }
 }
 
 template <typename R>

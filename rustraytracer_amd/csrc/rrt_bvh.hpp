@@ -135,19 +135,28 @@ RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill,
     const R bx_ = ((R)__uint_as_float(q0.x) - w.o.x) * w.inv_d.x;
     const R by_ = ((R)__uint_as_float(q0.y) - w.o.y) * w.inv_d.y;
     const R bz_ = ((R)__uint_as_float(q0.z) - w.o.z) * w.inv_d.z;
-    const uint32_t qlx = q1.x, qly = q1.y, qlz = q1.z, qhx = q1.w, qhy = q2.x, qhz = q2.y;
+    // Which bound of a slab the ray meets first depends on the sign of its direction only, so the entry ("near") and
+    // exit ("far") planes are picked once per node and axis on the packed words of all four children -- six selects --
+    // instead of a min and a max per child and axis; the two planes of an axis are then one packed FMA.
+    typedef R R2 __attribute__((ext_vector_type(2)));
+    const bool nx = w.inv_d.x < R(0), ny = w.inv_d.y < R(0), nz = w.inv_d.z < R(0);
+    const uint32_t qnx = nx ? q1.w : q1.x, qfx = nx ? q1.x : q1.w;
+    const uint32_t qny = ny ? q2.x : q1.y, qfy = ny ? q1.y : q2.x;
+    const uint32_t qnz = nz ? q2.y : q1.z, qfz = nz ? q1.z : q2.y;
     const int link[4] = {(int)q2.z, (int)q2.w, (int)q3.x, (int)q3.y};
     R dist[4];
     int child[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const R ax = (R)byte_to_float(qlx, k) * ax_ + bx_, bx = (R)byte_to_float(qhx, k) * ax_ + bx_;
-        const R ay = (R)byte_to_float(qly, k) * ay_ + by_, by = (R)byte_to_float(qhy, k) * ay_ + by_;
-        const R az = (R)byte_to_float(qlz, k) * az_ + bz_, bz = (R)byte_to_float(qhz, k) * az_ + bz_;
-        const R en = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-        const R ex = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz)) * widen;
+        R2 qx, qy, qz;  // (near, far)
+        qx.x = (R)byte_to_float(qnx, k); qx.y = (R)byte_to_float(qfx, k);
+        qy.x = (R)byte_to_float(qny, k); qy.y = (R)byte_to_float(qfy, k);
+        qz.x = (R)byte_to_float(qnz, k); qz.y = (R)byte_to_float(qfz, k);
+        const R2 tx = qx * ax_ + bx_, ty = qy * ay_ + by_, tz = qz * az_ + bz_;
+        const R en = fmax(fmax((R)tx.x, (R)ty.x), (R)tz.x);
+        const R ex = fmin(fmin((R)tx.y, (R)ty.y), (R)tz.y) * widen;
         child[k] = link[k];
-        const bool hit = en <= ex && ex >= R(0) && en <= w.acc.t && child[k] != BVH_NO_CHILD;
+        const bool hit = en <= fmin(ex, w.acc.t) && ex >= R(0) && child[k] != BVH_NO_CHILD;
         dist[k] = hit ? en : inf;
     }
     // sorting network for four keys

@@ -124,26 +124,36 @@ RRT_DEV uint32_t sample_key(uint32_t pixkey, uint32_t sample) {
 // Sampling", Pixar TM 13-01): a bijection for every key p, evaluated for one
 // index at a time, which replaces the reference's per-pixel shuffled tables
 // (src/sampler.rs:105-125).  w = next_pow2(l) - 1.
+// (i & w) >> s for w = 2^k - 1 is a bit-field extract: one instruction (v_bfe_u32) instead of two.
+RRT_DEV uint32_t masked_shr(uint32_t i, uint32_t k, uint32_t s) {
+    const int width = (int)k - (int)s;  // (signed max: scalar arithmetic has no saturating subtract)
+    return __builtin_amdgcn_ubfe(i, s, (uint32_t)(width > 0 ? width : 0));
+}
+
 RRT_DEV uint32_t permute(uint32_t i, uint32_t l, uint32_t w, uint32_t p) {
 #ifdef RRT_EXP_CHEAPHASH
     return (i ^ p) & w;
 #endif
+    // k = bits of w.  The field widths are wave-uniform scalar arithmetic; the empty asm keeps it next to its use
+    // (hoisted out of a kernel's main loop the five widths would occupy scalar registers for the whole kernel).
+    uint32_t k = (uint32_t)__builtin_popcount(w);
+    asm volatile("" : "+s"(k));
     do {
         i ^= p;
         i *= 0xe170893dU;
         i ^= p >> 16;
-        i ^= (i & w) >> 4;
+        i ^= masked_shr(i, k, 4);
         i ^= p >> 8;
         i *= 0x0929eb3fU;
         i ^= p >> 23;
-        i ^= (i & w) >> 1;
+        i ^= masked_shr(i, k, 1);
         i *= 1U | p >> 27;
         i *= 0x6935fa69U;
-        i ^= (i & w) >> 11;
+        i ^= masked_shr(i, k, 11);
         i *= 0x74dcb303U;
-        i ^= (i & w) >> 2;
+        i ^= masked_shr(i, k, 2);
         i *= 0x9e501cc3U;
-        i ^= (i & w) >> 2;
+        i ^= masked_shr(i, k, 2);
         i *= 0xc860a3dfU;
         i &= w;
         i ^= i >> 5;

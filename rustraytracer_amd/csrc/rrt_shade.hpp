@@ -19,9 +19,9 @@ RRT_DEV V3<R> reflect(V3<R> v, V3<R> n) {
     return mk<R>(v.x - n.x * k, v.y - n.y * k, v.z - n.z * k);
 }
 
+// ratio = eta_i / eta_t, which the caller has at hand
 template <typename R>
-RRT_DEV R fresnel(R cos_i, R eta_i, R eta_t) {
-    R ratio = eta_i * Num<R>::rcp(eta_t);  // (f32: v_rcp_f32, 1 ulp; an IEEE divide costs ten instructions)
+RRT_DEV R fresnel(R cos_i, R eta_i, R eta_t, R ratio) {
     R sin2_t = ratio * ratio * (R(1) - cos_i * cos_i);
     if (sin2_t > R(1)) return R(1);
     R cos_t = Num<R>::sqrt(R(1) - sin2_t);
@@ -162,10 +162,12 @@ RRT_DEV bool scatter_with(Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u
         V3<R> on = inside ? mk<R>(-n.x, -n.y, -n.z) : n;
         R eta_i = inside ? m.param : R(1);
         R eta_t = inside ? R(1) : m.param;
-        R eta = eta_i * Num<R>::rcp(eta_t);
+        // eta_i / eta_t and its inverse square come with the material (the host divides once, in f64):
+        // r = 1 / ior, g = 1 / (1/ior)^2, b = 1 / ior^2
+        R eta = inside ? m.param : m.r;
         R cos_theta = -dot(p.d, on);
         R r = draw_1d();
-        R F = fresnel<R>(cos_theta, eta_i, eta_t);
+        R F = fresnel<R>(cos_theta, eta_i, eta_t, eta);
         R pdf, w;
         if (r < F) {
             dir = reflect(p.d, on);
@@ -178,7 +180,7 @@ RRT_DEV bool scatter_with(Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u
             R k = eta * cos_theta - cos_t2;
             dir = mk<R>(eta * p.d.x + k * on.x, eta * p.d.y + k * on.y, eta * p.d.z + k * on.z);
             pdf = R(1) - F;
-            w = Num<R>::rcp(eta * eta);
+            w = inside ? m.b : m.g;  // 1 / eta^2
         }
         if (pdf <= Num<R>::eps()) return false;
         if (Num<R>::abs(dot(dir, n)) < Num<R>::eps()) return false;

@@ -61,7 +61,7 @@ struct ShadeRec {
 // One material per object (src/material.rs:286-315).
 template <typename R>
 struct MatRec {
-    R r, g, b;   // emission / albedo / specular
+    R r, g, b;   // emission / albedo / specular; dielectric: 1/ior, 1/(1/ior)^2, 1/ior^2 (eta and 1/eta^2, entering and leaving)
     R param;     // shininess / index of refraction
     int32_t type;
     int32_t emitter;  // |emission| > 1e-6  (src/tracers/utils.rs:52)

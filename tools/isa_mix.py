@@ -90,7 +90,7 @@ def find_symbol(lines, demangled):
     syms = [m.group(1) for ln in lines for m in [re.match(r"^(_Z\w+):", ln)] if m]
     names = subprocess.run(["c++filt"], input="\n".join(syms), capture_output=True, text=True).stdout.split("\n")
     for s, n in zip(syms, names):
-        if n.startswith("void rrt::" + demangled + "(") or n.startswith(demangled + "(") or demangled == s:
+        if n.startswith(("void rrt::" + demangled + "(", "rrt::" + demangled + "(", demangled + "(")) or demangled == s:
             return s
     raise SystemExit("no kernel named %r; have:\n%s" % (demangled, "\n".join(sorted(set(names)))))
 

@@ -4,7 +4,7 @@ set -u
 OUT=gpurun_out/pmcf_${1:-x}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --spp-side 64"
+BENCH="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --spp-side 64 ${*:2}"  # pmc_fused.sh TAG [more bench arguments, e.g. --workload smallpt]
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$OUT/sq1" -- $BENCH > "$OUT/sq1.log" 2>&1 || { echo fail1; tail -3 "$OUT/sq1.log"; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, collections, sys, json
