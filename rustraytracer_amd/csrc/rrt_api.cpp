@@ -607,11 +607,22 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
 
 // ------------------------------------------------------------------ wavefront pipeline
 // Paths per queue (56 bytes per path and queue).  Every trip costs one or two kernel launches with
-// their ramp-up and tail, and the persistent tree kernel ends every trip with half-empty waves, so
-// both want many rays per lane and trip: 16 Mi paths measured best for both (Cornell box through the
-// one-kernel-per-trip pipeline: 7.8 Gsamples/s at 1 Mi, 10.4 at 4 Mi, 11.2 at 16 Mi).
+// their ramp-up and tail, so both pipelines want many rays per lane and trip.  Linear-scan scenes: 16 Mi paths
+// measured best (Cornell box through the one-kernel-per-trip pipeline: 7.8 Gsamples/s at 1 Mi, 10.4 at 4 Mi,
+// 11.2 at 16 Mi).  Tree scenes: the persistent traversal kernel ends every trip with waves that drain their last
+// block of 64 rays at a fifth of their lanes, ~100 loop trips out of the ~700 a wave makes per 16 Mi rays; with 64 Mi
+// paths (7.5 GB of the 288 GB) that tail is a quarter as large: 5.15 -> 5.60 Grays/s on the million-triangle scene
+// (128 Mi and 256 Mi: 5.62, 5.63).  A device with less free memory gets smaller queues.
 const uint32_t kWfCapacityLinear = 1u << 24;
-const uint32_t kWfCapacityTree = 1u << 24;
+const uint32_t kWfCapacityTree = 1u << 26;
+const uint32_t kWfCapacityFloor = 1u << 20;
+
+size_t wavefront_bytes(size_t n) {
+    const size_t per_queue = n * (sizeof(float4) + sizeof(float2) + sizeof(float2) + sizeof(float4) + sizeof(uint2));
+    const size_t cursors = (n / 64) * sizeof(rrt::WfWaveCursor);
+    const size_t rows = (n / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
+    return 2 * per_queue + cursors + rows + 256 + 12 * 256;  // every array is padded to 256 bytes
+}
 
 int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity) {
     if (be->wf_mem && be->wf_capacity == capacity) return RRT_OK;
@@ -622,11 +633,9 @@ int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity) {
         be->wf_capacity = 0;
     }
     const size_t n = capacity;
-    const size_t per_queue = n * (sizeof(float4) + sizeof(float2) + sizeof(float2) + sizeof(float4) + sizeof(uint2));
     const size_t cursors = (n / 64) * sizeof(rrt::WfWaveCursor);
     const size_t rows = (n / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
-    const size_t total = 2 * per_queue + cursors + rows + 256;
-    HIP_TRY(hipMalloc(&be->wf_mem, total));
+    HIP_TRY(hipMalloc(&be->wf_mem, wavefront_bytes(n)));
     char* p = (char*)be->wf_mem;
     auto take = [&p](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
     // capacity is a multiple of 1024, so every array below is a multiple of 256 bytes long except
@@ -660,10 +669,16 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
     uint32_t capacity = use_bvh ? kWfCapacityTree : kWfCapacityLinear;
     if (const char* e = getenv("RRT_DEBUG_WF_CAPACITY")) {  // experiments and tests
         long v = atol(e);
-        if (v >= 64 && v <= (1l << 26)) capacity = (uint32_t)v;
+        if (v >= 64 && v <= (1l << 28)) capacity = (uint32_t)v;
     }
     const uint32_t block = (uint32_t)rrt::WF_SHADE_BLOCK;
     if ((uint64_t)capacity > total) capacity = (uint32_t)total;
+    {   // the queues must leave the caller at least half of what is free (counting the queues this backend already holds)
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (be->wf_mem) free_b += wavefront_bytes(be->wf_capacity);
+        while (capacity > kWfCapacityFloor && wavefront_bytes(capacity) > free_b / 2) capacity /= 2;
+    }
     capacity = (capacity + block - 1) / block * block;
     int rc = ensure_wavefront_buffers(be, capacity);
     if (rc != RRT_OK) return rc;
