@@ -78,6 +78,15 @@ typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBV
  * precision is f32, FUSED otherwise.  Both trace the same paths for the same seed. */
 typedef enum rrt_pipeline { RRT_PIPELINE_AUTO = 0, RRT_PIPELINE_FUSED = 1, RRT_PIPELINE_WAVEFRONT = 2 } rrt_pipeline;
 
+/* Estimator switches.  0 everywhere in parity runs: the reference implements connect() for s = 0 only
+ * (emission found by the camera path, src/tracers/utils.rs:115-121) and panics for s > 0 (utils.rs:122-124).
+ * RRT_RENDER_NEE adds the s = 1 strategy the reference leaves open: at every Lambertian or Phong vertex one point
+ * on an emissive primitive is sampled (lights chosen in proportion to area x emission, points uniform in area)
+ * and connected through a shadow ray; emission found by a scattered ray then counts only after a mirror or
+ * dielectric bounce or for the camera ray itself, so every light path is still counted once.  Same expected
+ * image, less noise with small lights.  Fused pipeline only; emissive planes (infinite area) are refused. */
+typedef enum rrt_render_flags { RRT_RENDER_NEE = 1 } rrt_render_flags;
+
 /* One primitive in the order the reference's linear scan visits it:
  * objects in [[objects]] order (src/scene.rs:39), faces in file order inside a
  * mesh (src/shapes/mesh.rs:32).  object_id = index into scene.objects,
@@ -130,7 +139,7 @@ typedef struct rrt_render_desc {
     uint32_t precision;        /* rrt_precision */
     uint32_t accel;            /* rrt_accel */
     uint32_t pipeline;         /* rrt_pipeline */
-    uint32_t reserved;
+    uint32_t flags;            /* rrt_render_flags, 0 = the reference's estimator */
 } rrt_render_desc;
 
 /* [post_processing] (src/renderer.rs:27-32). tone_mapping: 0 none, 1 reinhard. */

@@ -684,6 +684,155 @@ typedef struct {
     uint64_t rays_live; /* closest-hit queries made with a non-zero throughput */
 } trace_counters;
 
+/* ---- next-event estimation (rrt_render_desc.flags & RRT_RENDER_NEE).  NOT part of the reference: its connect()
+ * panics for s > 0 (src/tracers/utils.rs:122-124).  This is the CPU statement of the estimator include/rrt.h
+ * describes, written for checking the device kernels: same light table, same draws in the same order. */
+enum { LIGHT_TRIANGLE = 0, LIGHT_PGRAM = 1, LIGHT_SPHERE = 2 };
+typedef struct {
+    int type;
+    v3 v0, e1, e2, n, le; /* sphere: v0 = centre, e1.x = radius */
+    double inv_pdf;       /* area / probability of choosing this light */
+    int32_t object_id, prim_id; /* the primitive it is (a part of) */
+} light_t;
+typedef struct {
+    light_t* l;
+    float* cdf;
+    size_t n;
+} light_table;
+
+static void lights_push_planar(light_table* lt, double* weight, double* area, int type, v3 v0, v3 e1, v3 e2, const rrt_material* m, const rrt_prim* p) {
+    v3 c = vcross(e1, e2);
+    double len = vmag(c);
+    double a = type == LIGHT_TRIANGLE ? 0.5 * len : len;
+    if (!(a > 0.0)) return;
+    light_t* l = &lt->l[lt->n];
+    memset(l, 0, sizeof(*l));
+    l->type = type;
+    l->v0 = v0; l->e1 = e1; l->e2 = e2;
+    l->n = vmul(c, 1.0 / len);
+    l->le = ld3(m->rgb);
+    l->object_id = (int32_t)p->object_id;
+    l->prim_id = (int32_t)p->prim_id;
+    area[lt->n] = a;
+    weight[lt->n] = a * fmax(m->rgb[0], fmax(m->rgb[1], m->rgb[2]));
+    lt->n++;
+}
+
+/* every primitive of an emitting object in scan order; a parallelogram is one light, any other quad the two triangles
+ * (v0, v1, v3) and (v2, v3, v1) of the reference's test (src/shapes/quadrilateral.rs:56-117); chosen in proportion
+ * to area x largest emission component */
+static int lights_build(const rrt_scene_desc* sc, light_table* lt) {
+    memset(lt, 0, sizeof(*lt));
+    lt->l = (light_t*)calloc(2 * (size_t)sc->n_prims + 1, sizeof(light_t));
+    lt->cdf = (float*)calloc(2 * (size_t)sc->n_prims + 1, sizeof(float));
+    double* weight = (double*)calloc(2 * (size_t)sc->n_prims + 1, sizeof(double));
+    double* area = (double*)calloc(2 * (size_t)sc->n_prims + 1, sizeof(double));
+    if (!lt->l || !lt->cdf || !weight || !area) { free(weight); free(area); return -1; }
+    for (uint32_t i = 0; i < sc->n_prims; ++i) {
+        const rrt_prim* p = &sc->prims[i];
+        const rrt_material* m = &sc->materials[p->object_id];
+        if (m->type != RRT_MAT_EMISSIVE || !(vmag(ld3(m->rgb)) > 1e-6)) continue;
+        const double* v = p->v;
+        if (p->type == RRT_PRIM_PLANE) { free(weight); free(area); return -2; } /* no area to sample */
+        if (p->type == RRT_PRIM_SPHERE) {
+            double a = 4.0 * 3.14159265358979323846 * v[3] * v[3];
+            if (!(a > 0.0)) continue;
+            light_t* l = &lt->l[lt->n];
+            memset(l, 0, sizeof(*l));
+            l->type = LIGHT_SPHERE;
+            l->v0 = ld3(v);
+            l->e1 = V(v[3], 0, 0);
+            l->le = ld3(m->rgb);
+            l->object_id = (int32_t)p->object_id;
+            l->prim_id = (int32_t)p->prim_id;
+            area[lt->n] = a;
+            weight[lt->n] = a * fmax(m->rgb[0], fmax(m->rgb[1], m->rgb[2]));
+            lt->n++;
+        } else if (p->type == RRT_PRIM_TRIANGLE) {
+            lights_push_planar(lt, weight, area, LIGHT_TRIANGLE, ld3(v), vsub(ld3(v + 3), ld3(v)), vsub(ld3(v + 6), ld3(v)), m, p);
+        } else {
+            v3 v0 = ld3(v), v1 = ld3(v + 3), v2 = ld3(v + 6), v3_ = ld3(v + 9);
+            v3 gap = vsub(vadd(v0, v2), vadd(v1, v3_));
+            double scale = vmag(vsub(v1, v0)) + vmag(vsub(v3_, v0));
+            if (vmag(gap) <= 1e-12 * scale) {
+                lights_push_planar(lt, weight, area, LIGHT_PGRAM, v0, vsub(v1, v0), vsub(v3_, v0), m, p);
+            } else {
+                lights_push_planar(lt, weight, area, LIGHT_TRIANGLE, v0, vsub(v1, v0), vsub(v3_, v0), m, p);
+                lights_push_planar(lt, weight, area, LIGHT_TRIANGLE, v2, vsub(v3_, v2), vsub(v1, v2), m, p);
+            }
+        }
+    }
+    double total = 0.0, run = 0.0;
+    for (size_t i = 0; i < lt->n; ++i) total += weight[i];
+    for (size_t i = 0; i < lt->n; ++i) {
+        double prob = total > 0.0 ? weight[i] / total : 1.0 / (double)lt->n;
+        run += prob;
+        lt->l[i].inv_pdf = prob > 0.0 ? area[i] / prob : 0.0;
+        lt->cdf[i] = i + 1 == lt->n ? 1.0f : (float)run;
+    }
+    free(weight);
+    free(area);
+    return 0;
+}
+
+static void lights_free(light_table* lt) {
+    free(lt->l);
+    free(lt->cdf);
+    lt->l = NULL; lt->cdf = NULL; lt->n = 0;
+}
+
+/* f32_kernels: the device's f32 uniforms and its table are single precision; the point and the geometry terms are
+ * still evaluated in f64 here */
+static int light_sample(const light_table* lt, v3 x, double pick, double u, double v, v3* wi, double* dist, v3* le_w, const light_t** which) {
+    if (lt->n == 0) return 0;
+    size_t k = lt->n - 1;
+    for (size_t i = 0; i < lt->n; ++i) if (pick < (double)lt->cdf[i]) { k = i; break; }
+    const light_t* l = &lt->l[k];
+    *which = l;
+    v3 y, ny;
+    if (l->type == LIGHT_SPHERE) {
+        double z = 1.0 - 2.0 * u;
+        double r = sqrt(fmax(1.0 - z * z, 0.0));
+        double phi = 2.0 * ORACLE_PI * v;
+        ny = V(r * cos(phi), r * sin(phi), z);
+        y = vadd(l->v0, vmul(ny, l->e1.x));
+    } else {
+        double a = u, b = v;
+        if (l->type == LIGHT_TRIANGLE) {
+            double su = sqrt(u);
+            a = su * (1.0 - v);
+            b = su * v;
+        }
+        y = vadd(l->v0, vadd(vmul(l->e1, a), vmul(l->e2, b)));
+        ny = l->n;
+    }
+    v3 to = vsub(y, x);
+    double d2 = vdot(to, to);
+    if (!(d2 > 0.0)) return 0;
+    *dist = sqrt(d2);
+    *wi = vmul(to, 1.0 / *dist);
+    double w = fabs(vdot(ny, *wi)) * l->inv_pdf / d2;
+    *le_w = vmul(l->le, w);
+    return 1;
+}
+
+/* bxdf(wo, wi) |cos| of the lobe materials for a given wi, zero where mat_scatter could not have produced wi
+ * (pdf <= 1e-6 is rejected by the tracer) */
+static v3 lobe_bxdf_cos(const rrt_material* m, const ray_t* ray_in, v3 normal, v3 wi) {
+    double k = 0.0;
+    if (m->type == RRT_MAT_LAMBERTIAN) {
+        double c = vdot(wi, normal) * FRAC_1_PI;
+        if (c > 1e-6) k = c;
+    } else {
+        double c = vdot(wi, reflect(ray_in->d, normal));
+        if (c > 0.0) {
+            double cs = pow(c, m->param);
+            if (cs * (m->param + 1.0) * FRAC_1_PI * 0.5 > 1e-6) k = cs * (m->param + 2.0) * FRAC_1_PI * 0.5 * fabs(vdot(wi, normal));
+        }
+    }
+    return vmul(ld3(m->rgb), k);
+}
+
 /* MonteCarloPathTracer::trace  src/tracers/mcpt.rs:20-43 over
  * generate_camera_vertices  src/tracers/utils.rs:16-91 and connect (s = 0)
  * src/tracers/utils.rs:101-127.  Vertex generation stops at the first emissive
@@ -691,10 +840,11 @@ typedef struct {
  * t-1 (depth = t-2 never exceeds max_depth-1), so the sum over t is
  * beta * emission of the last vertex if it is emissive, else zero. */
 static v3 trace(const rrt_scene_desc* sc, const ray_t* camera_ray, sampler_t* sampler,
-                uint32_t min_depth, uint32_t max_depth, trace_counters* cnt) {
+                uint32_t min_depth, uint32_t max_depth, trace_counters* cnt, const light_table* lights) {
     v3 beta = V(1.0, 1.0, 1.0);
     ray_t ray = *camera_ray;
     v3 color = V(0, 0, 0);
+    int lights_sampled = 0; /* NEE: the previous vertex has already counted the lights */
     for (uint32_t depth = 0; depth < max_depth; ++depth) {
         hit_t hit;
         cnt->rays++;
@@ -703,7 +853,7 @@ static v3 trace(const rrt_scene_desc* sc, const ray_t* camera_ray, sampler_t* sa
         const rrt_material* material = &sc->materials[hit.object_id];
         v3 emission = mat_emission(material);
         if (vmag(emission) > 1e-6) {
-            color = vadd(color, vmulv(beta, emission));
+            if (!(lights && lights_sampled)) color = vadd(color, vmulv(beta, emission));
             break;
         }
         double continue_prob = depth > min_depth ? fmin(max_component(beta), 1.0) : 1.0;
@@ -712,6 +862,35 @@ static v3 trace(const rrt_scene_desc* sc, const ray_t* camera_ray, sampler_t* sa
         ray_t sr;
         double pdf;
         cnt->bounces[material->type < 5 ? material->type : 0]++;
+        if (lights && depth + 1 < max_depth) {
+            /* (a vertex whose scattered ray would never be traced connects to nothing either) */
+            if (material->type == RRT_MAT_LAMBERTIAN || material->type == RRT_MAT_PHONG) {
+                double pick = sampler_get_1d(sampler), lu, lv;
+                sampler_get_2d(sampler, &lu, &lv);
+                v3 wi, le_w;
+                double dist;
+                const light_t* l;
+                if (light_sample(lights, hit.p, pick, lu, lv, &wi, &dist, &le_w, &l)) {
+                    v3 f = lobe_bxdf_cos(material, &ray, hit.normal, wi);
+                    if (f.x != 0.0 || f.y != 0.0 || f.z != 0.0) {
+                        ray_t shadow;
+                        shadow.o = hit.p; shadow.d = wi;
+                        hit_t sh;
+                        cnt->rays++;
+                        if (beta.x != 0.0 || beta.y != 0.0 || beta.z != 0.0) cnt->rays_live++;
+                        /* unblocked: nothing on the way, or the first thing on the way is the flat light's own primitive (a
+                         * bent quad reports the distance to its first triangle's plane, not to the sampled point; a sphere
+                         * hides its own far side), or it is not nearer than the point */
+                        if (!scene_intersect(sc, &shadow, &sh) || (l->type != LIGHT_SPHERE && sh.object_id == l->object_id && sh.prim_id == l->prim_id) ||
+                            sh.t >= dist * (1.0 - 1e-4))
+                            color = vadd(color, vmulv(vmulv(beta, f), le_w));
+                    }
+                }
+                lights_sampled = 1;
+            } else {
+                lights_sampled = 0;
+            }
+        }
         if (!mat_scatter(material, &ray, hit.p, hit.normal, sampler, &sr, &pdf)) break;
         if (pdf <= 1e-6) break;
         double cos_theta = fabs(vdot(sr.d, hit.normal));
@@ -734,6 +913,7 @@ typedef struct {
     uint64_t samples, rays, rays_live, bounces[5], nonfinite;
     int failed;
     int device_numbers;
+    const light_table* lights; /* NULL: the reference's estimator */
 } render_job;
 
 /* One 16x16 tile: src/renderer.rs:104-140 */
@@ -776,7 +956,7 @@ static void render_tile(render_job* job, size_t tile_index, trace_counters* cnt,
                 double u = ((double)x + u_offset + 0.5) / (double)rd->width;
                 double v = 1.0 - ((double)y + v_offset + 0.5) / (double)rd->height;
                 ray_t ray = create_ray(&job->scene->camera, u, v);
-                color = vadd(color, trace(job->scene, &ray, &sampler, rd->min_depth, rd->max_depth, cnt));
+                color = vadd(color, trace(job->scene, &ray, &sampler, rd->min_depth, rd->max_depth, cnt, job->lights));
                 (*samples)++;
                 if (sampler.current_sample + 1 >= s_end) break;
                 if (!sampler_start_next_sample(&sampler)) break;
@@ -837,6 +1017,12 @@ static int render_accumulate_impl(const rrt_scene_desc* scene, const rrt_render_
     job.rd = rd;
     job.rgb_sum = rgb_sum;
     job.device_numbers = device_numbers;
+    light_table lights;
+    memset(&lights, 0, sizeof(lights));
+    if (rd->flags & RRT_RENDER_NEE) {
+        if (lights_build(scene, &lights) != 0) { lights_free(&lights); return -1; }
+        job.lights = &lights;
+    }
     job.tiles_x = (rd->width + 15) / 16;
     job.tile_count = job.tiles_x * ((rd->height + 15) / 16);
     pthread_mutex_init(&job.lock, NULL);
@@ -852,6 +1038,7 @@ static int render_accumulate_impl(const rrt_scene_desc* scene, const rrt_render_
     for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
     free(th);
     pthread_mutex_destroy(&job.lock);
+    lights_free(&lights);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->samples = job.samples;
@@ -1022,7 +1209,7 @@ int oracle_trace_samples(const rrt_scene_desc* scene, const rrt_render_desc* rd,
     memset(&cnt, 0, sizeof(cnt));
     for (size_t i = 0; i < n; ++i) {
         ray_t ray = create_ray(&scene->camera, u[i], v[i]);
-        v3 c = trace(scene, &ray, &s, rd->min_depth, rd->max_depth, &cnt);
+        v3 c = trace(scene, &ray, &s, rd->min_depth, rd->max_depth, &cnt, NULL);
         st3(rgb + 3 * i, c);
     }
     sampler_free(&s);

@@ -20,6 +20,7 @@ SAMPLER_RANDOM, SAMPLER_STRATIFIED = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH = 0, 1, 2
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
+RENDER_NEE = 1  # rrt_render_flags
 INTERSECT_STATIC_MAX_RAYS = 65536
 
 # numpy views of the plain-data structs (bulk construction of large scenes)
@@ -65,7 +66,7 @@ class RenderDesc(C.Structure):
         ("precision", C.c_uint32),
         ("accel", C.c_uint32),
         ("pipeline", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("flags", C.c_uint32),
     ]
 
 

@@ -468,7 +468,7 @@ class RenderConfig:
         return self.spp + 1 if self.sampler_type == _abi.SAMPLER_RANDOM else self.spp
 
     def render_desc(self, sample_begin=0, sample_end=None, seed=None, precision=_abi.PRECISION_F32,
-                    accel=_abi.ACCEL_AUTO, pipeline=_abi.PIPELINE_AUTO):
+                    accel=_abi.ACCEL_AUTO, pipeline=_abi.PIPELINE_AUTO, flags=0):
         d = _abi.RenderDesc()
         d.width, d.height = self.width, self.height
         d.sampler_type, d.spp = self.sampler_type, self.spp
@@ -478,6 +478,7 @@ class RenderConfig:
         d.sample_end = self.samples_traced if sample_end is None else sample_end
         d.seed = self.seed if seed is None else seed
         d.precision, d.accel, d.pipeline = precision, accel, pipeline
+        d.flags = flags
         return d
 
     def post_desc(self):

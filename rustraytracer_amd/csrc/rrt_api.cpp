@@ -186,7 +186,10 @@ struct DeviceScene {
     std::vector<void*> allocs;
     rrt::SceneView<float> v32{};
     rrt::SceneView<double> v64{};
+    rrt::LightView<float> l32{};
+    rrt::LightView<double> l64{};
     bool has_bvh = false;
+    int n_unbounded_lights = 0;  // emissive planes: next-event estimation cannot sample them
     ~DeviceScene() {
         if (device >= 0) {
             int cur = 0;
@@ -233,8 +236,96 @@ int upload(DeviceScene* ds, const std::vector<T>& host, const T** out, hipStream
     return RRT_OK;
 }
 
+// Area lights for next-event estimation: every primitive of an emitting object, in scan order.  A parallelogram is
+// one light, any other quad the two triangles the reference's test covers it with ((v0, v1, v3) and (v2, v3, v1),
+// src/shapes/quadrilateral.rs:56-117).  Emissive planes have no area to sample: counted in n_unbounded.
+struct HostLights {
+    std::vector<rrt::LightRec<double>> recs;
+    std::vector<float> cdf;
+    int n_unbounded = 0;
+};
+
+void build_lights(const rrt_scene* sc, HostLights& out) {
+    std::vector<double> weight, area;
+    auto planar = [&](int type, D3 v0, D3 e1, D3 e2, const rrt_material& m, size_t prim) {
+        rrt::LightRec<double> l;
+        std::memset(&l, 0, sizeof(l));
+        l.type = type;
+        l.prim = (int32_t)prim;
+        D3 c = cross(e1, e2);
+        const double len = std::sqrt(dot(c, c));
+        const double a = type == rrt::LIGHT_TRIANGLE ? 0.5 * len : len;
+        if (!(a > 0.0)) return;  // a degenerate face emits nothing
+        D3 n = c * (1.0 / len);
+        l.v0[0] = v0.x; l.v0[1] = v0.y; l.v0[2] = v0.z;
+        l.e1[0] = e1.x; l.e1[1] = e1.y; l.e1[2] = e1.z;
+        l.e2[0] = e2.x; l.e2[1] = e2.y; l.e2[2] = e2.z;
+        l.n[0] = n.x; l.n[1] = n.y; l.n[2] = n.z;
+        for (int k = 0; k < 3; ++k) l.le[k] = m.rgb[k];
+        out.recs.push_back(l);
+        area.push_back(a);
+        weight.push_back(a * std::max(m.rgb[0], std::max(m.rgb[1], m.rgb[2])));
+    };
+    for (size_t pi = 0; pi < sc->prims.size(); ++pi) {
+        const rrt_prim& p = sc->prims[pi];
+        const rrt_material& m = sc->materials[p.object_id];
+        const double mag = std::sqrt(m.rgb[0] * m.rgb[0] + m.rgb[1] * m.rgb[1] + m.rgb[2] * m.rgb[2]);
+        if (m.type != RRT_MAT_EMISSIVE || !(mag > 1e-6)) continue;
+        const double* v = p.v;
+        if (p.type == RRT_PRIM_PLANE) {
+            out.n_unbounded += 1;
+        } else if (p.type == RRT_PRIM_SPHERE) {
+            rrt::LightRec<double> l;
+            std::memset(&l, 0, sizeof(l));
+            l.type = rrt::LIGHT_SPHERE;
+            l.prim = (int32_t)pi;
+            l.v0[0] = v[0]; l.v0[1] = v[1]; l.v0[2] = v[2];
+            l.e1[0] = v[3];
+            for (int k = 0; k < 3; ++k) l.le[k] = m.rgb[k];
+            const double a = 4.0 * 3.14159265358979323846 * v[3] * v[3];
+            if (!(a > 0.0)) continue;
+            out.recs.push_back(l);
+            area.push_back(a);
+            weight.push_back(a * std::max(m.rgb[0], std::max(m.rgb[1], m.rgb[2])));
+        } else if (p.type == RRT_PRIM_TRIANGLE) {
+            planar(rrt::LIGHT_TRIANGLE, d3(v), d3(v + 3) - d3(v), d3(v + 6) - d3(v), m, pi);
+        } else {
+            D3 v0 = d3(v), v1 = d3(v + 3), v2 = d3(v + 6), v3 = d3(v + 9);
+            D3 gap = (v0 + v2) - (v1 + v3);
+            const double scale = std::sqrt(dot(v1 - v0, v1 - v0)) + std::sqrt(dot(v3 - v0, v3 - v0));
+            if (std::sqrt(dot(gap, gap)) <= 1e-12 * scale) {
+                planar(rrt::LIGHT_PGRAM, v0, v1 - v0, v3 - v0, m, pi);
+            } else {
+                planar(rrt::LIGHT_TRIANGLE, v0, v1 - v0, v3 - v0, m, pi);
+                planar(rrt::LIGHT_TRIANGLE, v2, v3 - v2, v1 - v2, m, pi);
+            }
+        }
+    }
+    double total = 0.0;
+    for (double w : weight) total += w;
+    double run = 0.0;
+    for (size_t i = 0; i < out.recs.size(); ++i) {
+        const double prob = total > 0.0 ? weight[i] / total : 1.0 / (double)out.recs.size();
+        run += prob;
+        out.recs[i].inv_pdf = prob > 0.0 ? area[i] / prob : 0.0;
+        out.cdf.push_back(i + 1 == out.recs.size() ? 1.0f : (float)run);
+    }
+}
+
 template <typename R>
-int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view,
+rrt::LightRec<R> narrow(const rrt::LightRec<double>& a) {
+    rrt::LightRec<R> o;
+    for (int k = 0; k < 3; ++k) {
+        o.v0[k] = (R)a.v0[k]; o.e1[k] = (R)a.e1[k]; o.e2[k] = (R)a.e2[k]; o.n[k] = (R)a.n[k]; o.le[k] = (R)a.le[k];
+    }
+    o.inv_pdf = (R)a.inv_pdf;
+    o.type = a.type;
+    o.prim = a.prim;
+    return o;
+}
+
+template <typename R>
+int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view, rrt::LightView<R>& lview,
               const std::vector<rrt::PrimRec<double>>& prims, const std::vector<rrt::ShadeRec<double>>& shade,
               const std::vector<rrt::MatRec<double>>& mats, hipStream_t stream) {
     std::vector<rrt::PrimRec<R>> p(prims.size());
@@ -286,6 +377,15 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view,
     if ((rc = upload(ds, runs, &view.runs, stream)) != RRT_OK) return rc;
     if ((rc = upload(ds, pairs, &view.pairs, stream)) != RRT_OK) return rc;
     view.n_runs = (int32_t)(runs.size() / 4);
+    HostLights hl;
+    build_lights(sc, hl);
+    std::vector<rrt::LightRec<R>> lights(hl.recs.size());
+    for (size_t i = 0; i < hl.recs.size(); ++i) lights[i] = narrow<R>(hl.recs[i]);
+    std::memset(&lview, 0, sizeof(lview));
+    if ((rc = upload(ds, lights, &lview.lights, stream)) != RRT_OK) return rc;
+    if ((rc = upload(ds, hl.cdf, &lview.cdf, stream)) != RRT_OK) return rc;
+    lview.n = (int32_t)lights.size();
+    ds->n_unbounded_lights = hl.n_unbounded;
     HIP_TRY(hipStreamSynchronize(stream));  // the staging vectors die here
     return RRT_OK;
 }
@@ -306,8 +406,8 @@ int device_scene(rrt_backend* be, const rrt_scene* sc_const, DeviceScene** out) 
     std::vector<rrt::MatRec<double>> mats(sc->materials.size());
     for (size_t i = 0; i < sc->prims.size(); ++i) prepare_prim(sc->prims[i], prims[i], shade[i]);
     for (size_t i = 0; i < sc->materials.size(); ++i) prepare_material(sc->materials[i], mats[i]);
-    int rc = fill_view<float>(ds, sc, ds->v32, prims, shade, mats, be->stream);
-    if (rc == RRT_OK) rc = fill_view<double>(ds, sc, ds->v64, prims, shade, mats, be->stream);
+    int rc = fill_view<float>(ds, sc, ds->v32, ds->l32, prims, shade, mats, be->stream);
+    if (rc == RRT_OK) rc = fill_view<double>(ds, sc, ds->v64, ds->l64, prims, shade, mats, be->stream);
     if (rc != RRT_OK) {
         delete ds;
         return rc;
@@ -562,6 +662,9 @@ int validate_render_desc(const rrt_render_desc* d) {
     if (d->precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", d->precision);
     if (d->accel > RRT_ACCEL_LBVH) return fail(RRT_ERR_INVALID, "unknown accel %u", d->accel);
     if (d->pipeline > RRT_PIPELINE_WAVEFRONT) return fail(RRT_ERR_INVALID, "unknown pipeline %u", d->pipeline);
+    if (d->flags & ~(uint32_t)RRT_RENDER_NEE) return fail(RRT_ERR_INVALID, "unknown render flags 0x%x", d->flags);
+    if ((d->flags & RRT_RENDER_NEE) && d->pipeline == RRT_PIPELINE_WAVEFRONT)
+        return fail(RRT_ERR_UNSUPPORTED, "next-event estimation runs in the fused pipeline only");
     return RRT_OK;
 }
 
@@ -582,6 +685,7 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
         while ((1u << rp.x_shift) < rp.x_strata) rp.x_shift++;
     }
     rp.perm_mask = next_pow2_mask(desc->spp);
+    rp.flags = (desc->flags & RRT_RENDER_NEE) ? rrt::RENDER_FLAG_NEE : 0u;
     rp.min_depth = desc->min_depth;
     rp.max_depth = desc->max_depth;
     rp.sample_begin = (uint32_t)desc->sample_begin;
@@ -919,8 +1023,11 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     if ((rc = resolve_accel(be, scene, ds, desc->accel, &use_bvh)) != RRT_OK) return rc;
     // AUTO: tree traversal wants many waves in flight, which the register-lean closest-hit kernel of
     // the wavefront pipeline has; a scan over a few primitives is fastest with the path in registers
+    const bool nee = (desc->flags & RRT_RENDER_NEE) != 0;
+    if (nee && ds->n_unbounded_lights > 0)
+        return fail(RRT_ERR_UNSUPPORTED, "next-event estimation cannot sample the scene's %d emissive plane(s)", ds->n_unbounded_lights);
     const bool wavefront = desc->pipeline == RRT_PIPELINE_WAVEFRONT ||
-                           (desc->pipeline == RRT_PIPELINE_AUTO && use_bvh && scene->prims.size() > kAutoWavefrontThreshold &&
+                           (desc->pipeline == RRT_PIPELINE_AUTO && !nee && use_bvh && scene->prims.size() > kAutoWavefrontThreshold &&
                             desc->precision == RRT_PRECISION_F32 && desc->max_depth <= rrt::WF_MAX_DEPTH);
 
     const size_t n_pixels = (size_t)desc->width * desc->height;
@@ -951,9 +1058,9 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         if ((rc = render_wavefront(be, ds->v32, use_bvh, rp, counters)) != RRT_OK) return rc;
     } else if (desc->max_depth > 0) {
         if (desc->precision == RRT_PRECISION_F64)
-            HIP_TRY(rrt::launch_render_fused(ds->v64, use_bvh, rp, n_blocks, be->stream));
+            HIP_TRY(rrt::launch_render_fused(ds->v64, ds->l64, use_bvh, rp, n_blocks, be->stream));
         else
-            HIP_TRY(rrt::launch_render_fused(ds->v32, use_bvh, rp, n_blocks, be->stream));
+            HIP_TRY(rrt::launch_render_fused(ds->v32, ds->l32, use_bvh, rp, n_blocks, be->stream));
     }
     HIP_TRY(hipEventRecord(be->ev1, be->stream));
 

@@ -74,9 +74,12 @@ intersect_kernel(SceneView<R> sv, size_t n, const double* __restrict__ a, const 
 // every bounce (primitive -> surface, object -> material) have LDS latency.
 constexpr int FUSED_LDS_PRIMS = 64;
 
-template <typename R, bool BVH, bool LDS_TABLES>
+// NEE: next-event estimation (RRT_RENDER_NEE) as a separate instantiation, so that the kernels of the reference's
+// estimator carry none of it: after the hit processing a lane at a Lambertian or Phong vertex samples a light and
+// traces the shadow ray (a second closest-hit query in the same trip).
+template <typename R, bool BVH, bool LDS_TABLES, bool NEE = false>
 __global__ void __launch_bounds__(256)
-render_fused(SceneView<R> sv, RenderParams rp) {
+render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
     __shared__ ShadeRec<R> s_shade[LDS_TABLES ? FUSED_LDS_PRIMS : 1];
     __shared__ MatRec<R> s_mats[LDS_TABLES ? FUSED_LDS_PRIMS : 1];
     if (LDS_TABLES) {
@@ -110,6 +113,8 @@ render_fused(SceneView<R> sv, RenderParams rp) {
     // wave-uniform event counters: bumped by ballots taken outside the divergent
     // regions, so they stay in scalar registers
     uint32_t c_rays = 0, c_nonfinite = 0, c_samples = 0;
+    uint32_t shadow_rays = 0;       // per lane (NEE only)
+    bool lights_sampled = false;    // NEE: the path's previous vertex sampled the lights, so an emitter found now adds nothing
     HitCounters hc{0, 0};
     BounceCounters bc{{0, 0, 0, 0, 0}};
 
@@ -134,9 +139,36 @@ render_fused(SceneView<R> sv, RenderParams rp) {
             if (g >= 0) {
                 const ShadeRec<R> sh = LDS_TABLES ? s_shade[g] : sv.shade[g];
                 m = LDS_TABLES ? s_mats[sh.object_id] : sv.mats[sh.object_id];
-                mode = process_hit<R>(rp, path, sh, m, t, acc, n, bad, counted);
+                mode = process_hit<R>(rp, path, sh, m, t, acc, n, bad, counted, !(NEE && lights_sampled));
             }
 #endif
+            if (NEE) {
+                if (mode == MAT_LAMBERTIAN || mode == MAT_PHONG) {
+                    // (process_hit has moved path.o to the vertex; path.d is still the incoming direction)
+                    const R pick = get_1d<R>(path.smp, rp, true);
+                    R lu, lv;
+                    get_draw<R>(path.smp, rp, true, lu, lv);
+                    V3<R> wi, le_w;
+                    R dist;
+                    int light_prim;
+                    if (sample_light<R>(lights, path.o, pick, lu, lv, wi, dist, le_w, light_prim)) {
+                        const V3<R> f = lobe_bxdf_cos<R>(mode, path.d, n, m, wi);
+                        if (f.x != R(0) || f.y != R(0) || f.z != R(0)) {
+                            R ts;
+                            const int gs = closest_hit<R, BVH>(sv, path.o, wi, ts, hc);
+                            shadow_rays += 1;
+                            if (gs < 0 || gs == light_prim || ts >= dist * (R(1) - nee_shadow_slack<R>())) {
+                                const V3<R> c = mk<R>(path.beta.x * f.x * le_w.x, path.beta.y * f.y * le_w.y, path.beta.z * f.z * le_w.z);
+                                bad = bad || !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
+                                acc = acc + c;
+                            }
+                        }
+                    }
+                    lights_sampled = true;
+                } else if (mode != MODE_NEW) {
+                    lights_sampled = false;  // mirror, glass: the next vertex is found by the scattered ray alone
+                }
+            }
         }
         c_nonfinite += (uint32_t)__popcll(__ballot(bad));
 #pragma unroll
@@ -246,9 +278,14 @@ render_fused(SceneView<R> sv, RenderParams rp) {
             path.beta = mk<R>(1, 1, 1);
             path.depth = 0;
             have_ray = true;
+            lights_sampled = false;
         } else if (mode != MODE_NEW) {
             have_ray = scatter<R>(path, mode, n, m, u2, v2);
         }
+    }
+    if (NEE) {
+        for (int off = 32; off > 0; off >>= 1) shadow_rays += __shfl_xor(shadow_rays, off);
+        c_rays += shadow_rays;
     }
     if (!BVH) {
         hc.prim_tests = c_rays * (uint32_t)sv.n_prims;  // a linear scan tests every primitive
@@ -369,24 +406,31 @@ hipError_t launch_intersect(const SceneView<double>& sv, bool bvh, bool primary,
 }
 
 template <typename R>
-static hipError_t launch_render_fused_t(const SceneView<R>& sv, bool bvh, const RenderParams& rp, int n_blocks,
+static hipError_t launch_render_fused_t(const SceneView<R>& sv, const LightView<R>& lv, bool bvh, const RenderParams& rp, int n_blocks,
                                         hipStream_t stream) {
     // RRT_DEBUG_LDS_BYTES: occupancy experiments only (unused dynamic LDS caps the blocks per CU)
     static const size_t lds = [] { const char* e = getenv("RRT_DEBUG_LDS_BYTES"); return e ? (size_t)atol(e) : (size_t)0; }();
     const bool tables = sv.n_prims <= FUSED_LDS_PRIMS && sv.n_objects <= FUSED_LDS_PRIMS;
+    if (rp.flags & RENDER_FLAG_NEE) {
+        if (bvh)
+            hipLaunchKernelGGL((render_fused<R, true, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
+        else
+            hipLaunchKernelGGL((render_fused<R, false, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
+        return hipGetLastError();
+    }
     if (bvh)
-        hipLaunchKernelGGL((render_fused<R, true, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
+        hipLaunchKernelGGL((render_fused<R, true, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
     else if (tables)
-        hipLaunchKernelGGL((render_fused<R, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
+        hipLaunchKernelGGL((render_fused<R, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
     else
-        hipLaunchKernelGGL((render_fused<R, false, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp);
+        hipLaunchKernelGGL((render_fused<R, false, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
     return hipGetLastError();
 }
-hipError_t launch_render_fused(const SceneView<float>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
-    return launch_render_fused_t<float>(sv, bvh, rp, n_blocks, s);
+hipError_t launch_render_fused(const SceneView<float>& sv, const LightView<float>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
+    return launch_render_fused_t<float>(sv, lv, bvh, rp, n_blocks, s);
 }
-hipError_t launch_render_fused(const SceneView<double>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
-    return launch_render_fused_t<double>(sv, bvh, rp, n_blocks, s);
+hipError_t launch_render_fused(const SceneView<double>& sv, const LightView<double>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
+    return launch_render_fused_t<double>(sv, lv, bvh, rp, n_blocks, s);
 }
 
 template <typename R>

@@ -20,8 +20,8 @@ hipError_t launch_intersect(const SceneView<float>& sv, bool bvh, bool primary, 
 hipError_t launch_intersect(const SceneView<double>& sv, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s);
 
-hipError_t launch_render_fused(const SceneView<float>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
-hipError_t launch_render_fused(const SceneView<double>& sv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
+hipError_t launch_render_fused(const SceneView<float>& sv, const LightView<float>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
+hipError_t launch_render_fused(const SceneView<double>& sv, const LightView<double>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
 
 hipError_t launch_sampler_values(const RenderParams& rp, uint32_t pixel, float* out, hipStream_t stream);
 

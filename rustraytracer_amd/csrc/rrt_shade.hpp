@@ -81,9 +81,11 @@ enum : int { MODE_NEW = 0 };
 // new ray is never traced and nothing it computed can reach the image.
 // `sh` is the ShadeRec of the primitive that was hit and `m` the MatRec of its object (the caller
 // fetches them: from HBM, or from the copy a kernel keeps in LDS for a small scene).
+// count_emission = false: the emitter still ends the path but adds nothing (next-event estimation has already
+// counted the light from the previous vertex).
 template <typename R>
 RRT_DEV int process_hit(const RenderParams& rp, Path<R>& p, const ShadeRec<R>& sh, const MatRec<R>& m, R t, V3<R>& acc,
-                        V3<R>& n, bool& bad, int& counted) {
+                        V3<R>& n, bool& bad, int& counted, bool count_emission = true) {
     V3<R> P = mk<R>(p.o.x + t * p.d.x, p.o.y + t * p.d.y, p.o.z + t * p.d.z);
     n = mk<R>(sh.nx, sh.ny, sh.nz);
     if (sh.type == PRIM_SPHERE) {  // (point - center) / radius, src/shapes/sphere.rs:87
@@ -94,6 +96,7 @@ RRT_DEV int process_hit(const RenderParams& rp, Path<R>& p, const ShadeRec<R>& s
         // an Emissive surface ends the path either way: as an emitter
         // (utils.rs:52-54) or because its scatter returns None (material.rs:44-46)
         V3<R> c = mk<R>(p.beta.x * m.r, p.beta.y * m.g, p.beta.z * m.b);
+        if (!count_emission) c = mk<R>(0, 0, 0);
         bad = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
         acc = acc + c;
         return MODE_NEW;
@@ -201,5 +204,78 @@ template <typename R>
 RRT_DEV bool scatter(Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u, R v) {
     return scatter_with<R>(p, mode, n, m, u, v, [&]() { return u; });
 }
+
+// ---------------------------------------------------------------- next-event estimation (RRT_RENDER_NEE)
+// The strategy the reference's connect() leaves unimplemented (s = 1, src/tracers/utils.rs:122-124): at a vertex
+// with a lobe material one point y on an emitter is sampled and joined to the vertex x by a shadow ray.
+//
+// sample_light: light `pick` in [0,1) selects through the cumulative table, (u, v) the point on it.  Returns the
+// unit direction x -> y, the distance, and  Le |n_y . wi| / |y - x|^2 / pdf_area(y)  (emitters radiate from both
+// sides, as Material::emission has no facing test, src/material.rs:52-54).
+template <typename R>
+RRT_DEV bool sample_light(const LightView<R>& lv, V3<R> x, R pick, R u, R v, V3<R>& wi, R& dist, V3<R>& le_w, int& prim) {
+    if (lv.n <= 0) return false;
+    int lo = 0, hi = lv.n - 1;  // first light whose cumulative probability exceeds pick (the last if none)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pick < (R)lv.cdf[mid]) hi = mid;
+        else lo = mid + 1;
+    }
+    const LightRec<R> l = lv.lights[lo];
+    prim = l.type == LIGHT_SPHERE ? -2 : l.prim;  // a sphere hides its own far side: no exemption for it
+    V3<R> y, ny;
+    if (l.type == LIGHT_SPHERE) {
+        const R z = R(1) - R(2) * u;
+        const R r = Num<R>::sqrt(fmax(R(1) - z * z, R(0)));
+        R sp, cp;
+        Num<R>::sincos2pi(v, sp, cp);
+        ny = mk<R>(r * cp, r * sp, z);
+        y = mk<R>(l.v0[0] + l.e1[0] * ny.x, l.v0[1] + l.e1[0] * ny.y, l.v0[2] + l.e1[0] * ny.z);
+    } else {
+        R a = u, b = v;
+        if (l.type == LIGHT_TRIANGLE) {  // uniform in the triangle: (1 - sqrt(u)) v0 + sqrt(u) (1 - v) v1 + sqrt(u) v v2
+            const R su = Num<R>::sqrt(u);
+            a = su * (R(1) - v);
+            b = su * v;
+        }
+        y = mk<R>(l.v0[0] + a * l.e1[0] + b * l.e2[0], l.v0[1] + a * l.e1[1] + b * l.e2[1], l.v0[2] + a * l.e1[2] + b * l.e2[2]);
+        ny = mk<R>(l.n[0], l.n[1], l.n[2]);
+    }
+    const V3<R> to = y - x;
+    const R d2 = dot(to, to);
+    if (!(d2 > R(0))) return false;
+    dist = Num<R>::sqrt(d2);
+    wi = to * (R(1) / dist);
+    const R w = Num<R>::abs(dot(ny, wi)) * l.inv_pdf / d2;
+    le_w = mk<R>(l.le[0] * w, l.le[1] * w, l.le[2] * w);
+    return true;
+}
+
+// bxdf(wo, wi) |cos| of the two lobe materials for a GIVEN direction wi, zero where Material::scatter could not
+// have produced wi (its pdf <= 1e-6 rejects, src/tracers/utils.rs:72): the same light transport as sampling the lobe.
+//   Lambertian     albedo / pi * (n . wi)                          for n . wi / pi > 1e-6   (src/material.rs:67-91)
+//   PhongSpecular  spec (s + 2) / (2 pi) c^s |n . wi|, c = r . wi  for c^s (s + 1) / (2 pi) > 1e-6   (src/material.rs:104-142)
+template <typename R>
+RRT_DEV V3<R> lobe_bxdf_cos(int mode, V3<R> d_in, V3<R> n, const MatRec<R>& m, V3<R> wi) {
+    R k = R(0);
+    if (mode == MAT_LAMBERTIAN) {
+        const R c = dot(wi, n) * Num<R>::inv_pi();
+        if (c > Num<R>::eps()) k = c;
+    } else {
+        const R c = dot(wi, reflect(d_in, n));
+        if (c > R(0)) {
+            const R cs = Num<R>::pow(c, m.param);
+            if (cs * (m.param + R(1)) * Num<R>::inv_pi() * R(0.5) > Num<R>::eps())
+                k = cs * (m.param + R(2)) * Num<R>::inv_pi() * R(0.5) * Num<R>::abs(dot(wi, n));
+        }
+    }
+    return mk<R>(m.r * k, m.g * k, m.b * k);
+}
+
+// A shadow ray is unblocked if nothing is on its way, if the first thing on its way is the flat light's own primitive
+// (`prim` of sample_light: a bent quad reports the distance to its first triangle's plane, not to the sampled point),
+// or if that thing is not nearer than dist (1 - slack).
+template <typename R>
+RRT_DEV R nee_shadow_slack() { return R(1e-4); }
 
 }  // namespace rrt

@@ -117,6 +117,24 @@ struct alignas(64) WideNode {
     int32_t pad1[2];
 };
 
+// One area light = one emissive primitive (a general quad gives two triangles), for next-event estimation
+// (RRT_RENDER_NEE; the reference's connect() stops at s = 0, src/tracers/utils.rs:115-124).
+//   LIGHT_TRIANGLE  point = v0 + (1 - sqrt(u)) e1 ... uniform in the triangle (v0, v0 + e1, v0 + e2)
+//   LIGHT_PGRAM     point = v0 + u e1 + v e2
+//   LIGHT_SPHERE    v0 = centre, e1[0] = radius; point uniform on the surface
+// inv_pdf = area / (probability of choosing this light); lights are chosen with probability proportional to
+// area x largest emission component (LightView::cdf).
+enum : int { LIGHT_TRIANGLE = 0, LIGHT_PGRAM = 1, LIGHT_SPHERE = 2 };
+template <typename R>
+struct LightRec {
+    R v0[3], e1[3], e2[3];
+    R n[3];       // unit normal (planar lights)
+    R le[3];      // emitted radiance
+    R inv_pdf;
+    int32_t type;
+    int32_t prim;  // scan-order index of the primitive it is (a part of)
+};
+
 template <typename R>
 struct SceneView {
     R cam_o[3];    // camera origin
@@ -141,6 +159,16 @@ struct SceneView {
     int32_t n_linear_prims;
 };
 
+// The area lights of a scene: a kernel argument of its own, read by the next-event-estimation kernels only (as fields
+// of SceneView they cost the other kernels scalar registers: +83 v_readlane in the fused kernel, 3-5 % of its speed).
+template <typename R>
+struct LightView {
+    const LightRec<R>* lights;
+    const float* cdf;     // n, non-decreasing, last = 1
+    int32_t n;
+    int32_t pad;
+};
+
 struct RenderParams {
     uint32_t width, height;
     uint32_t sampler_type, spp, x_strata, y_strata;
@@ -155,11 +183,13 @@ struct RenderParams {
     uint32_t seed_lo, seed_hi;
     float inv_width, inv_height;          // 1 / width, 1 / height
     float inv_spp, inv_x_strata, inv_y_strata;
-    uint32_t pad1;
+    uint32_t flags;            // RENDER_FLAG_*
     float* accum;              // width*height*3 radiance sums (atomicAdd target)
     unsigned long long* counters;  // see COUNTER_* below
     unsigned long long* work_counter;
 };
+
+enum : uint32_t { RENDER_FLAG_NEE = 1u };
 
 enum : int {
     COUNTER_RAYS = 0,

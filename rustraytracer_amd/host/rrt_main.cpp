@@ -29,6 +29,8 @@ const char* kUsage =
     "      --precision <f32|f64>            arithmetic of the kernels [default: f32]\n"
     "      --accel <auto|linear|lbvh>       closest-hit structure [default: auto]\n"
     "      --pipeline <auto|fused|wavefront> kernel organisation [default: auto]\n"
+    "      --next-event                     sample the lights at every Lambertian / Phong vertex (next-event estimation:\n"
+    "                                       same image in the mean, less noise with small lights; not the reference's estimator)\n"
     "      --stats-json <FILE>              write timings and counters of the run as JSON\n"
     "      --dump-scene <FILE>              write the flattened scene (binary) and exit without rendering\n"
     "  -h, --help                           Print help\n"
@@ -41,6 +43,7 @@ struct Args {
     bool has_seed = false;
     unsigned long long seed = 0;
     uint32_t precision = RRT_PRECISION_F32, accel = RRT_ACCEL_AUTO, pipeline = RRT_PIPELINE_AUTO;
+    uint32_t flags = 0;
 };
 
 [[noreturn]] void usage_error(const std::string& what) {
@@ -108,6 +111,8 @@ Args parse_args(int argc, char** argv) {
         } else if (arg == "--pipeline") {
             static const char* const n[] = {"auto", "fused", "wavefront"};
             a.pipeline = choice(arg, value(), n, 3);
+        } else if (arg == "--next-event") {
+            a.flags |= RRT_RENDER_NEE;
         } else if (arg == "--stats-json") {
             a.stats_json = value();
         } else if (arg == "--dump-scene") {
@@ -168,6 +173,7 @@ int run(const Args& a) {
     rs.render.precision = a.precision;
     rs.render.accel = a.accel;
     rs.render.pipeline = a.pipeline;
+    rs.render.flags = a.flags;
     if (a.has_seed) rs.render.seed = a.seed;
     const double t_load = seconds_since(t_start);
 
