@@ -129,24 +129,22 @@ def algorithmic_flops(stats, flat, table=FLOPS_PER_PRIM_TEST):
     return hit + sum(b * f for b, f in zip(stats["bounces"], FLOPS_PER_BOUNCE)) + stats["samples"] * FLOPS_RAYGEN
 
 
-def measured_traffic(workload, wavefront, precision):
-    """HBM-side bytes per launch from the kept PMC passes (profiles/hbm_traffic.json, written by
-    tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE runs): a kept figure of an earlier
-    profile of the same kernel and workload, not a counter of this run.  -> (bytes or None, source)."""
-    if precision != "f32":
-        return None, "no PMC pass kept for the f64 kernels"
-    key = workload + ("_wavefront" if wavefront and workload != "mesh_1m" else "")
+def measured_traffic(workload, wavefront, precision, rays_per_launch):
+    """HBM-side bytes per launch: the bytes per ray of the kept PMC passes of this workload (profiles/hbm_traffic.json,
+    written by tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE runs) times the rays of this run's
+    launch.  A kept figure of an earlier profile of the same kernels, not a counter of this run.
+    -> (bytes or None, source)."""
+    key = workload + ("_wavefront" if wavefront and workload != "mesh_1m" else "") + ("_f64" if precision != "f32" else "")
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             table = json.load(f)
     except Exception as e:  # noqa: BLE001
         return None, "profiles/hbm_traffic.json unreadable: %s" % e
     ent = table.get("workloads", {}).get(key)
-    if ent is None and key == "cornell" and "bytes_per_launch" in table:  # file layout of the first round
-        ent = table
     if ent is None:
         return None, "no PMC pass kept for %s" % key
-    return ent.get("bytes_per_launch"), "kept PMC figure, not measured in this run: %s (%s)" % (ent.get("source"), ent.get("note", ""))
+    return ent["bytes_per_ray"] * rays_per_launch, ("kept PMC figure, not measured in this run: %.1f B per ray (%s) x the rays of "
+                                                    "one step" % (ent["bytes_per_ray"], ent.get("source")))
 
 
 # ---------------------------------------------------------------------------- CPU baseline
@@ -331,7 +329,7 @@ def run_rank(args):
         kernel_s = tot["kernel_ms"] / 1e3
         achieved = flops / kernel_s / 1e12 if kernel_s > 0 else 0.0
         peak = PEAK_FP32_VALU_TFLOPS if args.precision == "f32" else PEAK_FP64_VALU_TFLOPS
-        traffic, traffic_source = measured_traffic(args.workload, wavefront, args.precision)
+        traffic, traffic_source = measured_traffic(args.workload, wavefront, args.precision, tot["rays"] / max(args.steps, 1))
         out = {
             "metric": "Msamples/s (whole node), %s MCPT" % METRIC_NAMES[args.workload],
             "value": all_samples / elapsed / 1e6,

@@ -3,7 +3,7 @@
    <tag>_kernel_stats.csv   the rocprofv3 --kernel-trace --stats table
    <tag>_pmc.csv            counter values per kernel: sum over the run's dispatches, all passes
    <tag>_summary.md         derived figures per kernel
-   hbm_traffic.json         (default workload only) bytes per launch of the fused render kernel, read by bench.py"""
+   hbm_traffic.json         HBM-side bytes per ray of the profiled workload (entry added or replaced), read by bench.py"""
 import collections
 import csv
 import glob
@@ -62,6 +62,7 @@ if bench:
     if "queue_traffic_algorithmic_GBps" in r:
         lines.append(f"* algorithmic queue traffic (88 B per ray): {r['queue_traffic_algorithmic_GBps']:.0f} GB/s")
 steps_total = (bench.get("steps", 0) + bench.get("warmup", 0)) or 1
+hbm_total, hbm_disp = [0.0, 0.0], [0]
 for k in sorted(kern, key=lambda k: -float(kern[k]["TotalDurationNs"])):
     r = kern[k]
     if float(r["Percentage"]) < 0.5:
@@ -99,10 +100,34 @@ for k in sorted(kern, key=lambda k: -float(kern[k]["TotalDurationNs"])):
         write_b = c.get("WRITE_SIZE", 0.0) * 1024
         lines.append(f"* HBM-side traffic over the run: FETCH_SIZE x2 (gfx950 correction) = {fetch_b/1e9:.3f} GB read, WRITE_SIZE = "
                      f"{write_b/1e9:.3f} GB written -> {(fetch_b+write_b)/total_s/1e9:.1f} GB/s while the kernel runs")
-        if k.startswith("render_fused") and bench.get("config", {}).get("workload", "").startswith("configs/cornell_box"):
-            n = disp[k].get("FETCH_SIZE", 1) or 1
-            json.dump({"bytes_per_launch": (fetch_b + write_b) / n, "fetch_bytes": fetch_b / n, "write_bytes": write_b / n,
-                       "source": f"profiles/{tag}_pmc.csv", "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB -> bytes, per launch"},
-                      open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+        hbm_total[0] += fetch_b
+        hbm_total[1] += write_b
+        hbm_disp[0] = max(hbm_disp[0], disp[k].get("FETCH_SIZE", 0), disp[k].get("WRITE_SIZE", 0))
+# HBM-side bytes per ray of this workload (all kernels of the run), kept for bench.py's roofline.traffic
+if bench and (hbm_total[0] or hbm_total[1]):
+    wl = bench.get("config", {}).get("workload", "")
+    name = {"configs/cornell_box": "cornell", "configs/smallpt": "smallpt", "configs/cornell_cube": "cornell_cube",
+            "configs/mesh_1m": "mesh_1m"}.get(wl.split("/scene.toml")[0], None)
+    if name:
+        if bench["config"]["pipeline"].startswith("wavefront") and name != "mesh_1m":
+            name += "_wavefront"
+        if bench.get("dtype") == "f64":
+            name += "_f64"
+        # rays of the profiled run: every launch of the run (warm-up + steps) traces the same rays
+        rays = bench["mrays_per_s"] * 1e6 * bench["ms_per_step"] * 1e-3 * (bench["steps"] + bench["warmup"])
+        path = os.path.join(dst, "hbm_traffic.json")
+        try:
+            table = json.load(open(path))
+        except Exception:
+            table = {}
+        if "workloads" not in table:
+            table = {"workloads": {}}
+        table["note"] = ("HBM-side bytes per ray from separate rocprofv3 --pmc passes (FETCH_SIZE x2, the gfx950 correction, "
+                         "+ WRITE_SIZE; KiB -> bytes), summed over all kernels of the profiled bench.py run and divided by the "
+                         "rays that run traced; bench.py multiplies by the rays of its own step")
+        table["workloads"][name] = {"bytes_per_ray": (hbm_total[0] + hbm_total[1]) / rays, "fetch_bytes_per_ray": hbm_total[0] / rays,
+                                    "write_bytes_per_ray": hbm_total[1] / rays, "rays_profiled": rays,
+                                    "source": f"profiles/{tag}_pmc.csv", "command": command}
+        json.dump(table, open(path, "w"), indent=1)
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
