@@ -581,7 +581,16 @@ static int mat_scatter(const rrt_material* m, const ray_t* ray_in, v3 hit_point,
         sampler_get_2d(sampler, &u, &v);
         double theta = acos(sqrt(1.0 - u));
         double phi = 2.0 * ORACLE_PI * v;
-        v3 nd = sampler->device_numbers == 2 ? to_world_f32_kernels(theta, phi, normal) : spherical_to_world(theta, phi, normal);
+        v3 nd;
+        if (sampler->device_numbers == 2) {
+            /* the f32 device kernels' cosine lobe: the normal plus a uniform point on the unit sphere (height 1 - 2u,
+             * azimuth 2 pi v), normalised -- the same density cos / pi as the reference's mapping */
+            double r = 2.0 * sqrt(fmax(u - u * u, 0.0));
+            v3 w = V(normal.x + r * cos(phi), normal.y + r * sin(phi), normal.z + (1.0 - 2.0 * u));
+            nd = vmul(w, 1.0 / sqrt(vdot(w, w)));
+        } else {
+            nd = spherical_to_world(theta, phi, normal);
+        }
         out->o = hit_point; out->d = nd;
         *pdf = vdot(nd, normal) * FRAC_1_PI;
         return 1;

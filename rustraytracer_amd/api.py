@@ -119,10 +119,24 @@ class Backend:
                 raise ValueError("rgb_sum must be a C-contiguous float32 array")
             if rgb_sum.size != render_desc.height * render_desc.width * 3:
                 raise ValueError("rgb_sum has the wrong size")
+        elif hasattr(rgb_sum, "data_ptr"):
+            self._check_tensor(rgb_sum, "float32", render_desc.height * render_desc.width * 3, "rgb_sum")
         st = _abi.Stats()
         _abi.check(self._lib, self._lib.rrt_render_accumulate(self.handle, scene.handle, C.byref(render_desc),
                                                                _ptr(rgb_sum), C.byref(st)))
         return rgb_sum, st.as_dict()
+
+    def _check_tensor(self, t, dtype, numel, what):
+        """A torch tensor handed to the library by address must be what the kernels assume: dtype, dense layout, size,
+        and (if it lives on a GPU) this backend's GPU."""
+        if str(t.dtype) != "torch." + dtype:
+            raise ValueError("%s must be a %s tensor, not %s" % (what, dtype, t.dtype))
+        if not t.is_contiguous():
+            raise ValueError("%s must be contiguous" % what)
+        if t.numel() != numel:
+            raise ValueError("%s has %d elements, expected %d" % (what, t.numel(), numel))
+        if t.device.type == "cuda" and t.device.index != self.device_id:
+            raise ValueError("%s is on %s, the backend renders on GPU %d" % (what, t.device, self.device_id))
 
     def sampler_values(self, render_desc, pixel):
         """Device sampler output for every sample index of the desc's range: float32 [n, 8]
@@ -151,8 +165,15 @@ class Backend:
         if isinstance(rgb_sum, np.ndarray):
             rgb_sum = np.ascontiguousarray(rgb_sum, dtype=np.float32)
         h, w = int(rgb_sum.shape[0]), int(rgb_sum.shape[1])
+        if hasattr(rgb_sum, "data_ptr"):
+            self._check_tensor(rgb_sum, "float32", h * w * 3, "rgb_sum")
         if out is None:
             out = np.empty((h, w, 3), dtype=np.uint8)
+        elif isinstance(out, np.ndarray):
+            if out.dtype != np.uint8 or not out.flags.c_contiguous or out.size != h * w * 3:
+                raise ValueError("out must be a C-contiguous uint8 array of %d elements" % (h * w * 3))
+        elif hasattr(out, "data_ptr"):
+            self._check_tensor(out, "uint8", h * w * 3, "out")
         _abi.check(self._lib, self._lib.rrt_postprocess(self.handle, _ptr(rgb_sum), int(spp_divisor),
                                                          C.byref(post_desc), w, h, _ptr(out)))
         return out

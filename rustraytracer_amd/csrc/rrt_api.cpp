@@ -578,14 +578,20 @@ int resolve_accel(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, uint32_
     return *use_bvh ? ensure_bvh(be, sc, ds) : RRT_OK;
 }
 
-bool is_device_pointer(const void* p) {
+// How a caller's buffer is used.  Kernels write in place only into plain device memory of the backend's own GPU:
+// the render kernels add with unsafe FP atomics, which are not guaranteed to take effect on managed or fine-grained
+// memory that may live on the host.  Managed memory and plain host memory are staged (both are host-readable);
+// device memory of ANOTHER GPU is refused.
+enum class PtrKind { Host, Device, OtherDevice };
+PtrKind classify_pointer(const rrt_backend* be, const void* p) {
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
     if (e != hipSuccess) {
         (void)hipGetLastError();  // plain host memory is reported as an error; clear it
-        return false;
+        return PtrKind::Host;
     }
-    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+    if (attr.type == hipMemoryTypeDevice) return attr.device == be->device ? PtrKind::Device : PtrKind::OtherDevice;
+    return PtrKind::Host;  // pinned host, managed, unregistered
 }
 
 int check_backend(rrt_backend* be) {
@@ -1031,7 +1037,9 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
                             desc->precision == RRT_PRECISION_F32 && desc->max_depth <= rrt::WF_MAX_DEPTH);
 
     const size_t n_pixels = (size_t)desc->width * desc->height;
-    const bool on_device = is_device_pointer(rgb_sum);
+    const PtrKind sum_kind = classify_pointer(be, rgb_sum);
+    if (sum_kind == PtrKind::OtherDevice) return fail(RRT_ERR_INVALID, "rgb_sum is device memory of another GPU than the backend's (%d)", be->device);
+    const bool on_device = sum_kind == PtrKind::Device;
     DevBuf staging;
     float* d_accum = rgb_sum;
     if (!on_device) {
@@ -1150,7 +1158,10 @@ int rrt_postprocess(rrt_backend* be, const float* rgb_sum, uint64_t spp_divisor,
     DevBuf in_stage, out_stage;
     const float* d_in = rgb_sum;
     uint8_t* d_out = rgb8;
-    const bool in_dev = is_device_pointer(rgb_sum), out_dev = is_device_pointer(rgb8);
+    const PtrKind in_kind = classify_pointer(be, rgb_sum), out_kind = classify_pointer(be, rgb8);
+    if (in_kind == PtrKind::OtherDevice || out_kind == PtrKind::OtherDevice)
+        return fail(RRT_ERR_INVALID, "rgb_sum / rgb8 is device memory of another GPU than the backend's (%d)", be->device);
+    const bool in_dev = in_kind == PtrKind::Device, out_dev = out_kind == PtrKind::Device;
     if (!in_dev) {
         HIP_TRY(in_stage.alloc(n * sizeof(float)));
         HIP_TRY(hipMemcpyAsync(in_stage.p, rgb_sum, n * sizeof(float), hipMemcpyHostToDevice, be->stream));

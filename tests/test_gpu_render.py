@@ -262,3 +262,28 @@ def test_render_argument_errors(gpu, cfg, cornell):
     d.width = 0
     with pytest.raises(api.RrtError):
         be.render_accumulate(sc, d)
+
+
+def test_accumulator_buffers_are_checked(gpu, cfg, cornell):
+    """A torch tensor goes to the kernels by address: a wrong dtype, a strided view or a wrong size must be refused
+    before that; a float32 CUDA tensor and a host array give the same sums."""
+    import torch
+
+    api, be = gpu
+    sc = api.Scene(cornell)
+    rc = cfg.stratified_config(32, 24, 2, 2, seed=3)
+    host, _ = be.render_accumulate(sc, rc.render_desc())
+    dev = torch.zeros((24, 32, 3), dtype=torch.float32, device="cuda:0")
+    be.render_accumulate(sc, rc.render_desc(), dev)
+    torch.cuda.synchronize()
+    assert np.allclose(dev.cpu().numpy(), host, rtol=1e-5, atol=1e-6)
+    with pytest.raises(ValueError):
+        be.render_accumulate(sc, rc.render_desc(), torch.zeros((24, 32, 3), dtype=torch.float64, device="cuda:0"))
+    with pytest.raises(ValueError):
+        be.render_accumulate(sc, rc.render_desc(), torch.zeros((24, 32, 6), dtype=torch.float32, device="cuda:0")[:, :, ::2])
+    with pytest.raises(ValueError):
+        be.render_accumulate(sc, rc.render_desc(), torch.zeros((24, 32), dtype=torch.float32, device="cuda:0"))
+    # pinned host memory is staged like any host buffer (the kernels' FP atomics are for device memory only)
+    pinned = torch.zeros((24, 32, 3), dtype=torch.float32).pin_memory()
+    be.render_accumulate(sc, rc.render_desc(), pinned)
+    assert np.allclose(pinned.numpy(), host, rtol=1e-5, atol=1e-6)
