@@ -274,7 +274,7 @@ static int prim_intersect(const rrt_prim* pr, const ray_t* ray, double t_min, do
  * (src/object.rs:14-23) and Mesh::intersect (src/shapes/mesh.rs:28-89) folded
  * in: the mesh loop starts from the scene's closest_so_far and shrinks it per
  * face, which is the same as one flat scan over the faces in scene order. */
-static int scene_intersect(const rrt_scene_desc* sc, const ray_t* ray, hit_t* best) {
+static int scene_intersect_scan(const rrt_scene_desc* sc, const ray_t* ray, hit_t* best) {
     int found = 0;
     double closest_so_far = 1.7976931348623157e308; /* f64::MAX */
     for (uint32_t i = 0; i < sc->n_prims; ++i) {
@@ -288,6 +288,217 @@ static int scene_intersect(const rrt_scene_desc* sc, const ray_t* ray, hit_t* be
         }
     }
     return found;
+}
+
+/* ---- a bounding-volume hierarchy for the ORACLE (test infrastructure; the reference has none, README.md lists it
+ * as an open item).  Scenes of a million triangles take the scan above ~10 ms per ray; with the tree the oracle can
+ * render them and be compared with the device.  The tree must return what the scan returns: the same primitive and
+ * the same t, including the scan's rule for equal t (sphere / plane / quad hits replace an earlier hit at equal t,
+ * triangle hits do not; src/shapes/ *.rs range tests).  tests/test_oracle_accel.py checks tree == scan.
+ *   - binary tree, median split of the centroids along the longest axis, leaves of <= 4 primitives;
+ *   - boxes from the vertices (sphere: centre +- radius), padded by 1e-9 of the scene size: a hit point lies on its
+ *     primitive up to rounding, far inside the padding;
+ *   - planes (unbounded) and quads that are not parallelograms (the reference's test accepts rays outside the
+ *     corners of a bent quad, see quadrilateral_intersect) stay in a list that is scanned for every ray. */
+typedef struct { double lo[3], hi[3]; int32_t left, right, first, count; } bvh_node; /* leaf: count > 0 */
+typedef struct {
+    const rrt_prim* prims_key; uint32_t n_prims_key; /* the scene it belongs to */
+    bvh_node* nodes; size_t n_nodes;
+    uint32_t* order;   /* primitive indices, leaves own ranges of it */
+    uint32_t* linear; size_t n_linear;
+} bvh_t;
+static bvh_t* g_accel = NULL;
+
+static void prim_bounds(const rrt_prim* p, double lo[3], double hi[3]) {
+    const double* v = p->v;
+    if (p->type == RRT_PRIM_SPHERE) {
+        for (int k = 0; k < 3; ++k) { lo[k] = v[k] - fabs(v[3]); hi[k] = v[k] + fabs(v[3]); }
+        return;
+    }
+    int nv = p->type == RRT_PRIM_TRIANGLE ? 3 : 4;
+    for (int k = 0; k < 3; ++k) { lo[k] = hi[k] = v[k]; }
+    for (int i = 1; i < nv; ++i)
+        for (int k = 0; k < 3; ++k) {
+            if (v[3 * i + k] < lo[k]) lo[k] = v[3 * i + k];
+            if (v[3 * i + k] > hi[k]) hi[k] = v[3 * i + k];
+        }
+}
+
+static int prim_in_tree(const rrt_prim* p) {
+    if (p->type == RRT_PRIM_PLANE) return 0;
+    if (p->type == RRT_PRIM_QUAD) {
+        v3 v0 = ld3(p->v), v1 = ld3(p->v + 3), v2 = ld3(p->v + 6), v3_ = ld3(p->v + 9);
+        v3 gap = vsub(vadd(v0, v2), vadd(v1, v3_));
+        double scale = vmag(vsub(v1, v0)) + vmag(vsub(v3_, v0));
+        if (!(vmag(gap) <= 1e-12 * scale)) return 0;
+    }
+    for (int i = 0; i < 12; ++i) if (!isfinite(p->v[i])) return 0;
+    return 1;
+}
+
+typedef struct { const double* cen; int axis; } bvh_sort_ctx;
+static bvh_sort_ctx g_sort; /* build is single-threaded */
+static int bvh_cmp(const void* a, const void* b) {
+    double x = g_sort.cen[3 * (size_t)*(const uint32_t*)a + g_sort.axis], y = g_sort.cen[3 * (size_t)*(const uint32_t*)b + g_sort.axis];
+    return x < y ? -1 : x > y ? 1 : (*(const uint32_t*)a < *(const uint32_t*)b ? -1 : 1);
+}
+
+static int32_t bvh_build_node(bvh_t* t, const double* plo, const double* phi, const double* cen, size_t first, size_t count) {
+    int32_t id = (int32_t)t->n_nodes++;
+    bvh_node* n = &t->nodes[id];
+    for (int k = 0; k < 3; ++k) { n->lo[k] = INFINITY; n->hi[k] = -INFINITY; }
+    double clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = first; i < first + count; ++i) {
+        size_t g = t->order[i];
+        for (int k = 0; k < 3; ++k) {
+            if (plo[3 * g + k] < n->lo[k]) n->lo[k] = plo[3 * g + k];
+            if (phi[3 * g + k] > n->hi[k]) n->hi[k] = phi[3 * g + k];
+            if (cen[3 * g + k] < clo[k]) clo[k] = cen[3 * g + k];
+            if (cen[3 * g + k] > chi[k]) chi[k] = cen[3 * g + k];
+        }
+    }
+    n->left = n->right = -1;
+    n->first = (int32_t)first;
+    n->count = (int32_t)count;
+    if (count <= 4) return id;
+    int axis = 0;
+    if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+    if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+    g_sort.cen = cen;
+    g_sort.axis = axis;
+    qsort(t->order + first, count, sizeof(uint32_t), bvh_cmp);
+    size_t half = count / 2;
+    int32_t l = bvh_build_node(t, plo, phi, cen, first, half);
+    int32_t r = bvh_build_node(t, plo, phi, cen, first + half, count - half);
+    n = &t->nodes[id];
+    n->left = l; n->right = r; n->count = 0;
+    return id;
+}
+
+void oracle_accel_free(void) {
+    if (!g_accel) return;
+    free(g_accel->nodes); free(g_accel->order); free(g_accel->linear);
+    free(g_accel);
+    g_accel = NULL;
+}
+
+/* Builds the tree for `scene` and makes every later closest-hit query on that scene (same primitive array) use it,
+ * until oracle_accel_free().  Not thread-safe against concurrent builds; renders only read it. */
+int oracle_accel_build(const rrt_scene_desc* scene) {
+    oracle_accel_free();
+    size_t n = scene->n_prims;
+    bvh_t* t = (bvh_t*)calloc(1, sizeof(bvh_t));
+    double* plo = (double*)malloc(sizeof(double) * 3 * (n + 1));
+    double* phi = (double*)malloc(sizeof(double) * 3 * (n + 1));
+    double* cen = (double*)malloc(sizeof(double) * 3 * (n + 1));
+    if (!t || !plo || !phi || !cen) { free(t); free(plo); free(phi); free(cen); return -1; }
+    t->prims_key = scene->prims;
+    t->n_prims_key = scene->n_prims;
+    t->order = (uint32_t*)malloc(sizeof(uint32_t) * (n + 1));
+    t->linear = (uint32_t*)malloc(sizeof(uint32_t) * (n + 1));
+    t->nodes = (bvh_node*)malloc(sizeof(bvh_node) * (2 * n + 2));
+    if (!t->order || !t->linear || !t->nodes) { free(plo); free(phi); free(cen); g_accel = t; oracle_accel_free(); return -1; }
+    size_t m = 0;
+    double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (size_t i = 0; i < n; ++i) {
+        if (!prim_in_tree(&scene->prims[i])) { t->linear[t->n_linear++] = (uint32_t)i; continue; }
+        prim_bounds(&scene->prims[i], plo + 3 * i, phi + 3 * i);
+        for (int k = 0; k < 3; ++k) {
+            cen[3 * i + k] = 0.5 * (plo[3 * i + k] + phi[3 * i + k]);
+            if (plo[3 * i + k] < slo[k]) slo[k] = plo[3 * i + k];
+            if (phi[3 * i + k] > shi[k]) shi[k] = phi[3 * i + k];
+        }
+        t->order[m++] = (uint32_t)i;
+    }
+    double size = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        if (m && shi[k] - slo[k] > size) size = shi[k] - slo[k];
+        if (m && fabs(slo[k]) > size) size = fabs(slo[k]);
+        if (m && fabs(shi[k]) > size) size = fabs(shi[k]);
+    }
+    double pad = 1e-9 * size + 1e-300;
+    for (size_t j = 0; j < m; ++j) {
+        size_t i = t->order[j];
+        for (int k = 0; k < 3; ++k) { plo[3 * i + k] -= pad; phi[3 * i + k] += pad; }
+    }
+    if (m) bvh_build_node(t, plo, phi, cen, 0, m);
+    free(plo); free(phi); free(cen);
+    g_accel = t;
+    return 0;
+}
+
+static int scene_intersect_scan(const rrt_scene_desc* sc, const ray_t* ray, hit_t* best);
+
+/* the scan's winner among equal-t hits, reconstructed from visits in any order: see the header of this section */
+typedef struct { double t; int64_t first, last_incl; hit_t h_first, h_last; } tie_acc;
+static void tie_consider(tie_acc* a, const rrt_scene_desc* sc, const ray_t* ray, uint32_t g) {
+    hit_t h;
+    /* t_max a little above the current best, so that a triangle AT the best distance (open interval in the
+     * reference) is still seen; anything beyond the best is then dropped here */
+    double tmax = a->t >= 1.7976931348623157e308 ? a->t : nextafter(a->t, INFINITY);
+    if (!prim_intersect(&sc->prims[g], ray, 0.001, tmax, &h)) return;
+    if (h.t > a->t) return;
+    h.object_id = (int32_t)sc->prims[g].object_id;
+    h.prim_id = (int32_t)sc->prims[g].prim_id;
+    int inclusive = sc->prims[g].type != RRT_PRIM_TRIANGLE;
+    if (h.t < a->t) {
+        a->t = h.t;
+        a->first = g; a->h_first = h;
+        a->last_incl = inclusive ? (int64_t)g : -1;
+        if (inclusive) a->h_last = h;
+    } else {
+        if ((int64_t)g < a->first) { a->first = g; a->h_first = h; }
+        if (inclusive && (int64_t)g > a->last_incl) { a->last_incl = g; a->h_last = h; }
+    }
+}
+
+static int bvh_intersect(const bvh_t* t, const rrt_scene_desc* sc, const ray_t* ray, hit_t* best) {
+    tie_acc a;
+    a.t = 1.7976931348623157e308;
+    a.first = a.last_incl = -1;
+    for (size_t i = 0; i < t->n_linear; ++i) tie_consider(&a, sc, ray, t->linear[i]);
+    if (t->n_nodes) {
+        int32_t stack[128];
+        int sp = 0;
+        stack[sp++] = 0;
+        const double o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};
+        while (sp) {
+            const bvh_node* n = &t->nodes[stack[--sp]];
+            double t0 = 0.0, t1 = a.t;
+            int miss = 0;
+            for (int k = 0; k < 3 && !miss; ++k) {
+                if (d[k] == 0.0) {
+                    if (o[k] < n->lo[k] || o[k] > n->hi[k]) miss = 1;
+                    continue;
+                }
+                double ta = (n->lo[k] - o[k]) / d[k], tb = (n->hi[k] - o[k]) / d[k];
+                if (ta > tb) { double x = ta; ta = tb; tb = x; }
+                /* widen by rounding of the two divisions */
+                ta -= 1e-12 * fabs(ta); tb += 1e-12 * fabs(tb);
+                if (ta > t0) t0 = ta;
+                if (tb < t1) t1 = tb;
+                if (t0 > t1) miss = 1;
+            }
+            if (miss) continue;
+            if (n->count > 0) {
+                for (int32_t i = 0; i < n->count; ++i) tie_consider(&a, sc, ray, t->order[n->first + i]);
+            } else if (sp + 2 <= 128) {
+                stack[sp++] = n->left;
+                stack[sp++] = n->right;
+            } else {
+                return scene_intersect_scan(sc, ray, best); /* never with a median-split tree (depth <= 32) */
+            }
+        }
+    }
+    if (a.first < 0) return 0;
+    *best = a.last_incl > a.first ? a.h_last : a.h_first;
+    return 1;
+}
+
+static int scene_intersect(const rrt_scene_desc* sc, const ray_t* ray, hit_t* best) {
+    if (g_accel && g_accel->prims_key == sc->prims && g_accel->n_prims_key == sc->n_prims)
+        return bvh_intersect(g_accel, sc, ray, best);
+    return scene_intersect_scan(sc, ray, best);
 }
 
 int oracle_intersect(const rrt_scene_desc* scene, size_t n, const double* origins,

@@ -24,6 +24,10 @@ int oracle_render_accumulate(const rrt_scene_desc* scene, const rrt_render_desc*
  * f32 kernels see them (24-bit uniforms) and with their lobe basis */
 int oracle_render_accumulate_device_numbers(const rrt_scene_desc* scene, const rrt_render_desc* rd,
                              double* rgb_sum, rrt_stats* stats, int n_threads, int f32_kernels);
+/* a bounding-volume hierarchy for the oracle's own closest-hit queries on `scene` (until oracle_accel_free): same
+ * results as its scan, for scenes the scan is too slow for */
+int oracle_accel_build(const rrt_scene_desc* scene);
+void oracle_accel_free(void);
 int oracle_postprocess(const double* rgb_sum, uint64_t spp_divisor, const rrt_post_desc* post,
                        uint32_t width, uint32_t height, uint8_t* rgb8, double* rgb_linear);
 

@@ -49,6 +49,8 @@ def lib():
                                          C.POINTER(C.c_uint8), _dp]
         L.oracle_trace_samples.argtypes = [C.POINTER(_abi.SceneDesc), C.POINTER(_abi.RenderDesc), C.c_size_t,
                                            _dp, _dp, _dp]
+        L.oracle_accel_build.argtypes = [C.POINTER(_abi.SceneDesc)]
+        L.oracle_accel_free.restype = None
         _lib = L
     return _lib
 
@@ -188,6 +190,23 @@ def trace_primary(scene, u, v):
     lib().oracle_trace_primary(C.byref(desc), n, up, vp, oid.ctypes.data_as(_i32p), pid.ctypes.data_as(_i32p),
                                t.ctypes.data_as(_dp))
     return oid, pid, t
+
+
+class accelerated:
+    """with accelerated(scene): the oracle's closest-hit queries on `scene` go through its own bounding-volume hierarchy
+    (same results as its scan, tests/test_oracle_accel.py) -- for scenes of many primitives."""
+
+    def __init__(self, scene):
+        self._desc = scene.desc()  # keeps the arrays the tree is keyed on alive
+
+    def __enter__(self):
+        if lib().oracle_accel_build(C.byref(self._desc)) != 0:
+            raise MemoryError("oracle_accel_build failed")
+        return self
+
+    def __exit__(self, *exc):
+        lib().oracle_accel_free()
+        return False
 
 
 def render_accumulate(scene, render_desc, n_threads=0, device_numbers=False):

@@ -219,3 +219,34 @@ def test_ties_and_degenerate_inputs_same_paths(gpu, O, cfg):
     assert frac <= 0.005 and rel_rays <= 1e-4
     frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_WAVEFRONT, "nasty wavefront")
     assert frac <= 0.005 and rel_rays <= 1e-4
+
+
+def test_million_triangle_scene_same_paths(gpu, O, cfg):
+    """configs/mesh_1m (998 290 primitives): the oracle, whose scan needs ~10 ms per ray here, goes through its own
+    bounding-volume hierarchy (tests/test_oracle_accel.py: the same hits as its scan) and draws the device's numbers;
+    the device renders through the GPU-built LBVH.  f64 fused kernel: the same image pixel by pixel; f32 product path
+    (wavefront pipeline, what the benchmark runs): the same paths up to f32 rounding flips."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_c5_assets
+    make_c5_assets.main()
+    api, be = gpu
+    flat = cfg.load_scene(os.path.join(ROOT, "configs", "mesh_1m", "scene.toml"))
+    assert flat.n_prims > 900000
+    sc = api.Scene(flat)
+    rc = cfg.stratified_config(192, 108, 2, 2, seed=71)
+    with O.accelerated(flat):
+        ref64, rst64 = O.render_accumulate(flat, rc.render_desc(), device_numbers=True)
+        ref32, rst32 = O.render_accumulate(flat, rc.render_desc(), device_numbers="f32")
+    dev, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64, accel=api.ACCEL_LBVH))
+    err = np.abs(dev.astype(np.float64) - ref64)
+    bad = int(np.any(err > 4e-7 * np.abs(ref64) + 1e-9, axis=-1).sum())
+    print("mesh_1m f64: pixels off %d of %d, rays %d / %d" % (bad, rc.width * rc.height, st["rays"], rst64["rays_live"]))
+    assert bad <= 6 and abs(st["rays"] - rst64["rays_live"]) <= 64
+    dev, st = be.render_accumulate(sc, rc.render_desc())  # AUTO: tree + wavefront pipeline, f32
+    off = np.any(np.abs(dev.astype(np.float64) - ref32) > 2e-5 * np.abs(ref32) + 1e-6, axis=-1)
+    rel_rays = abs(st["rays"] - rst32["rays_live"]) / rst32["rays_live"]
+    print("mesh_1m f32: pixels off %d of %d (%.2f %%), closest-hit queries differ by %.2e" % (off.sum(), off.size, 100 * off.mean(), rel_rays))
+    assert off.mean() <= 0.01 and rel_rays <= 1e-3
