@@ -14,6 +14,7 @@
 // prim_of_slot[slot] = index into the bounds arrays.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>  // rocPRIM uses ::memset in host code without including it
 
 #include <rocprim/rocprim.hpp>
@@ -104,34 +105,8 @@ collapse_kernel(BvhNode* __restrict__ nodes, int n, const int* __restrict__ rang
     if (c1 >= 0 && range_count[c1] <= leaf_max) nodes[i].c1 = ~(range_first[c1] | ((range_count[c1] - 1) << BVH_SLOT_BITS));
 }
 
-// Wide node i = binary node i with both children expanded, boxes quantised (see WideNode).
-__global__ void __launch_bounds__(256) widen_kernel(const BvhNode* __restrict__ nodes, int n, WideNode* __restrict__ wide) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    const BvhNode N = nodes[i];
-    float lo[4][3], hi[4][3];
-    int child[4];
-    int k = 0;
-    auto put = [&](const float* l, const float* h, int c) {
-        for (int a = 0; a < 3; ++a) { lo[k][a] = l[a]; hi[k][a] = h[a]; }
-        child[k] = c;
-        ++k;
-    };
-    if (N.c0 >= 0) {
-        const BvhNode C = nodes[N.c0];
-        put(C.lo0, C.hi0, C.c0);
-        put(C.lo1, C.hi1, C.c1);
-    } else {
-        put(N.lo0, N.hi0, N.c0);
-    }
-    if (N.c1 >= 0) {
-        const BvhNode C = nodes[N.c1];
-        put(C.lo0, C.hi0, C.c0);
-        put(C.lo1, C.hi1, C.c1);
-    } else {
-        put(N.lo1, N.hi1, N.c1);
-    }
-    const int used = k;
+// Quantises up to four child boxes onto the node's own grid (see WideNode) and writes the node.
+__device__ void write_wide_node(const float (*lo)[3], const float (*hi)[3], const int* child, int used, WideNode* out) {
     WideNode W;
     W.pad0 = 0;
     W.pad1[0] = W.pad1[1] = 0;
@@ -165,7 +140,94 @@ __global__ void __launch_bounds__(256) widen_kernel(const BvhNode* __restrict__ 
         W.qhi[a] = whi;
     }
     for (int c = 0; c < 4; ++c) W.child[c] = c < used ? child[c] : BVH_NO_CHILD;
-    wide[i] = W;
+    *out = W;
+}
+
+// Wide node i = binary node i with both children expanded, boxes quantised (see WideNode).
+__global__ void __launch_bounds__(256) widen_kernel(const BvhNode* __restrict__ nodes, int n, WideNode* __restrict__ wide) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const BvhNode N = nodes[i];
+    float lo[4][3], hi[4][3];
+    int child[4];
+    int k = 0;
+    auto put = [&](const float* l, const float* h, int c) {
+        for (int a = 0; a < 3; ++a) { lo[k][a] = l[a]; hi[k][a] = h[a]; }
+        child[k] = c;
+        ++k;
+    };
+    if (N.c0 >= 0) {
+        const BvhNode C = nodes[N.c0];
+        put(C.lo0, C.hi0, C.c0);
+        put(C.lo1, C.hi1, C.c1);
+    } else {
+        put(N.lo0, N.hi0, N.c0);
+    }
+    if (N.c1 >= 0) {
+        const BvhNode C = nodes[N.c1];
+        put(C.lo0, C.hi0, C.c0);
+        put(C.lo1, C.hi1, C.c1);
+    } else {
+        put(N.lo1, N.hi1, N.c1);
+    }
+    write_wide_node(lo, hi, child, k, &wide[i]);
+}
+
+// Greedy widening: the children of wide node i are found by opening, again and again, the internal child with the
+// largest surface area until there are four (or no internal child is left) -- a large child is the one rays are most
+// likely to enter, so opening it saves the most steps; opening both children of the binary node one level, as
+// widen_kernel does, spends slots on small children of lopsided subtrees.  Which binary nodes become wide nodes is
+// then known only top-down: state[i] = 1 marks a node whose turn it is, 2 a finished one; every launch handles the
+// marked nodes and marks their internal children, the host repeats it until a launch marks nothing.
+__global__ void __launch_bounds__(256)
+widen_greedy_kernel(const BvhNode* __restrict__ nodes, int n, WideNode* __restrict__ wide, int* __restrict__ state,
+                    int* __restrict__ marked) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    if (__hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) return;
+    float lo[4][3], hi[4][3];
+    int child[4];
+    int k = 0;
+    auto put = [&](int at, const float* l, const float* h, int c) {
+        for (int a = 0; a < 3; ++a) { lo[at][a] = l[a]; hi[at][a] = h[a]; }
+        child[at] = c;
+    };
+    {
+        const BvhNode N = nodes[i];
+        put(0, N.lo0, N.hi0, N.c0);
+        put(1, N.lo1, N.hi1, N.c1);
+        k = 2;
+    }
+    while (k < 4) {
+        int best = -1;
+        float best_area = -1.f;
+        for (int c = 0; c < k; ++c) {
+            if (child[c] < 0) continue;
+            const float dx = hi[c][0] - lo[c][0], dy = hi[c][1] - lo[c][1], dz = hi[c][2] - lo[c][2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > best_area) { best_area = area; best = c; }
+        }
+        if (best < 0) break;
+        const BvhNode C = nodes[child[best]];
+        put(best, C.lo0, C.hi0, C.c0);
+        put(k, C.lo1, C.hi1, C.c1);
+        ++k;
+    }
+    write_wide_node(lo, hi, child, k, &wide[i]);
+    int any = 0;
+    for (int c = 0; c < k; ++c)
+        if (child[c] >= 0) {
+            __hip_atomic_store(&state[child[c]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            any = 1;
+        }
+    __hip_atomic_store(&state[i], 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (any) __hip_atomic_store(marked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256) finished_flag_kernel(const int* __restrict__ state, int n, int* __restrict__ flag) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    flag[i] = state[i] == 2 ? 1 : 0;
 }
 
 // Wide node i is reached by rays iff binary node i sits at an even depth (odd levels are absorbed
@@ -296,13 +358,39 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
         LBVH_TRY(hipGetLastError());
     }
     LBVH_TRY(hipMalloc(&wide_tmp, sizeof(WideNode) * (size_t)(n - 1)));
-    hipLaunchKernelGGL(widen_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp);
-    LBVH_TRY(hipGetLastError());
-    // only about half of the wide nodes are ever visited: pack those (twice the useful nodes per cache line)
+    // only some of the binary nodes become wide nodes that rays visit: pack those (more useful nodes per cache line)
     int* flag = reinterpret_cast<int*>(flags);   // the refit flags are free again
     int* new_index = leaf_parent;                // and so is this array
-    hipLaunchKernelGGL(reachable_kernel, grid, block, 0, stream, node_parent, range_count, n, leaf_max, flag);
-    LBVH_TRY(hipGetLastError());
+    static const bool greedy = [] { const char* e = getenv("RRT_DEBUG_WIDEN_GREEDY"); return e ? atoi(e) != 0 : true; }();  // experiments
+    if (greedy) {
+        int* state = range_first;  // free after the collapse
+        int* marked = nullptr;
+        LBVH_TRY(hipMalloc(&marked, sizeof(int)));
+        auto drop = [&]() { (void)hipFree(marked); };
+        e = hipMemsetAsync(state, 0, sizeof(int) * n, stream);
+        const int one = 1;
+        if (e == hipSuccess) e = hipMemcpyAsync(state, &one, sizeof(int), hipMemcpyHostToDevice, stream);
+        for (int round = 0; e == hipSuccess; ++round) {
+            int again = 0;
+            e = hipMemsetAsync(marked, 0, sizeof(int), stream);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(widen_greedy_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp, state, marked);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&again, marked, sizeof(int), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess || !again) break;
+            if (round > 4 * 96) { e = hipErrorUnknown; break; }  // deeper than any radix tree over 63 + 32 bits
+        }
+        drop();
+        LBVH_TRY(e);
+        hipLaunchKernelGGL(finished_flag_kernel, grid, block, 0, stream, state, n, flag);
+        LBVH_TRY(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(widen_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp);
+        LBVH_TRY(hipGetLastError());
+        hipLaunchKernelGGL(reachable_kernel, grid, block, 0, stream, node_parent, range_count, n, leaf_max, flag);
+        LBVH_TRY(hipGetLastError());
+    }
     {
         size_t scan_bytes = 0;
         LBVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, new_index, 0, (size_t)(n - 1), rocprim::plus<int>(), stream));
