@@ -215,7 +215,7 @@ struct rrt_backend {
     int n_cu = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    unsigned long long* d_counters = nullptr;  // COUNTER_COUNT + 1 (the last one is the work counter)
+    unsigned long long* d_counters = nullptr;  // COUNTER_ROWS x COUNTER_COUNT + 1 (the last one is the work counter)
     // wavefront pipeline: queues and control block, allocated on first use and kept
     void* wf_mem = nullptr;
     uint32_t wf_capacity = 0;
@@ -675,7 +675,8 @@ int validate_render_desc(const rrt_render_desc* d) {
 }
 
 // Kernel-side view of a validated render description.
-rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
+// lanes: paths the device traces at once in the fused kernel (blocks x 256)
+rrt::RenderParams make_render_params(const rrt_render_desc* desc, uint64_t lanes) {
     const size_t n_pixels = (size_t)desc->width * desc->height;
     rrt::RenderParams rp;
     std::memset(&rp, 0, sizeof(rp));
@@ -698,10 +699,17 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc) {
     rp.n_samples = (uint32_t)(desc->sample_end - desc->sample_begin);
     // samples per work item: enough items to balance the tail, few enough to keep
     // the per-item atomics and the 32-bit item index negligible / valid
+    // 128 (96-160 measure the same at 16384 spp; 32 costs 2.3 % in bookkeeping, 2048 costs 15 %: four items per lane).
+    // A call with few samples per lane -- one GPU's share of a frame split over eight -- takes 64, so that every lane
+    // still gets ~15 items or more: 2025 spp of the Cornell box 18.8 -> 19.3 Gsamples/s, 4096 spp 20.3 -> 20.6.
     uint32_t target = 128;
+    if ((uint64_t)((rp.n_samples + 127) / 128) * n_pixels < 24 * lanes) target = 64;
     if (const char* e = getenv("RRT_DEBUG_CHUNK")) target = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 128;  // experiments
     uint32_t chunk = rp.n_samples < target ? rp.n_samples : target;
     while ((uint64_t)((rp.n_samples + chunk - 1) / chunk) * n_pixels >= (1ull << 31)) chunk *= 2;
+    // (Tried: the last two big items' worth of samples per lane in items of chunk / 2 ... chunk / 8, so that the lanes
+    //  run dry closer together.  No gain at 256 ... 16384 spp: the launch's fixed ~1.4 ms -- kernel time of the Cornell
+    //  box is 1.4 ms + 11.7 us per sample per pixel -- is not the last item's length.)
     rp.chunk = chunk;
     rp.n_chunks = (rp.n_samples + chunk - 1) / chunk;
     rp.n_items = (uint64_t)rp.n_chunks * n_pixels;
@@ -931,7 +939,7 @@ int rrt_backend_create(const char* name, int device_id, rrt_backend** out) {
     }
     if (e == hipSuccess) e = hipEventCreate(&be->ev0);
     if (e == hipSuccess) e = hipEventCreate(&be->ev1);
-    if (e == hipSuccess) e = hipMalloc((void**)&be->d_counters, sizeof(unsigned long long) * (rrt::COUNTER_COUNT + 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&be->d_counters, sizeof(unsigned long long) * (rrt::COUNTER_ROWS * rrt::COUNTER_COUNT + 1));
     if (e != hipSuccess) {
         rrt_backend_destroy(be);
         return fail(RRT_ERR_HIP, "backend set-up failed: %s", hipGetErrorString(e));
@@ -1048,12 +1056,12 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         HIP_TRY(hipMemsetAsync(d_accum, 0, n_pixels * 3 * sizeof(float), be->stream));
     }
 
-    rrt::RenderParams rp = make_render_params(desc);
+    rrt::RenderParams rp = make_render_params(desc, (uint64_t)be->n_cu * 8 * 256);
     rp.accum = d_accum;
     rp.counters = be->d_counters;
-    rp.work_counter = be->d_counters + rrt::COUNTER_COUNT;
+    rp.work_counter = be->d_counters + rrt::COUNTER_ROWS * rrt::COUNTER_COUNT;
 
-    HIP_TRY(hipMemsetAsync(be->d_counters, 0, sizeof(unsigned long long) * (rrt::COUNTER_COUNT + 1), be->stream));
+    HIP_TRY(hipMemsetAsync(be->d_counters, 0, sizeof(unsigned long long) * (rrt::COUNTER_ROWS * rrt::COUNTER_COUNT + 1), be->stream));
     // 8 blocks of 4 waves per CU is the most a CU holds; fewer lanes than items are never needed
     uint64_t max_blocks = (uint64_t)be->n_cu * 8;
     uint64_t want = (rp.n_items + 255) / 256;
@@ -1061,6 +1069,7 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     if (n_blocks < 1) n_blocks = 1;
 
     unsigned long long counters[rrt::COUNTER_COUNT + 1];
+    unsigned long long counter_rows[rrt::COUNTER_ROWS * rrt::COUNTER_COUNT];
     HIP_TRY(hipEventRecord(be->ev0, be->stream));
     if (desc->max_depth > 0 && wavefront) {
         if ((rc = render_wavefront(be, ds->v32, use_bvh, rp, counters)) != RRT_OK) return rc;
@@ -1072,8 +1081,9 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     }
     HIP_TRY(hipEventRecord(be->ev1, be->stream));
 
-    if (!wavefront || desc->max_depth == 0)
-        HIP_TRY(hipMemcpyAsync(counters, be->d_counters, sizeof(counters), hipMemcpyDeviceToHost, be->stream));
+    const bool fused_counters = !wavefront || desc->max_depth == 0;
+    if (fused_counters)
+        HIP_TRY(hipMemcpyAsync(counter_rows, be->d_counters, sizeof(counter_rows), hipMemcpyDeviceToHost, be->stream));
     std::vector<float> host_tmp;
     if (!on_device) {
         host_tmp.resize(n_pixels * 3);
@@ -1081,6 +1091,11 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
                                be->stream));
     }
     HIP_TRY(hipStreamSynchronize(be->stream));
+    if (fused_counters) {
+        for (int k = 0; k < rrt::COUNTER_COUNT; ++k) counters[k] = 0;
+        for (int r = 0; r < rrt::COUNTER_ROWS; ++r)
+            for (int k = 0; k < rrt::COUNTER_COUNT; ++k) counters[k] += counter_rows[r * rrt::COUNTER_COUNT + k];
+    }
     if (!on_device)
         for (size_t i = 0; i < n_pixels * 3; ++i) rgb_sum[i] += host_tmp[i];
     if (stats) {
@@ -1104,7 +1119,7 @@ int rrt_sampler_values(rrt_backend* be, const rrt_render_desc* desc, uint32_t pi
     if (!out_host) return fail(RRT_ERR_INVALID, "out is NULL");
     if ((rc = validate_render_desc(desc)) != RRT_OK) return rc;
     if (pixel >= desc->width * desc->height) return fail(RRT_ERR_INVALID, "pixel %u outside the image", pixel);
-    rrt::RenderParams rp = make_render_params(desc);
+    rrt::RenderParams rp = make_render_params(desc, (uint64_t)be->n_cu * 8 * 256);
     DevBuf buf;
     const size_t bytes = (size_t)rp.n_samples * 8 * sizeof(float);
     HIP_TRY(buf.alloc(bytes));

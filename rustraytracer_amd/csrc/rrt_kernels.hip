@@ -300,7 +300,8 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
     if (lane == 0) {
         const RenderParams RRT_CONSTANT* q = rpk;
         asm volatile("" : "+s"(q));
-        unsigned long long* counters = q->counters;
+        // (a row picked by the number of the wave's last item pool: spread, and already in a scalar register)
+        unsigned long long* counters = q->counters + (size_t)((pool_end >> 6) & (uint32_t)(COUNTER_ROWS - 1)) * COUNTER_COUNT;
         atomicAdd(&counters[COUNTER_RAYS], (unsigned long long)c_rays);
         atomicAdd(&counters[COUNTER_PRIM_TESTS], (unsigned long long)hc.prim_tests);
         atomicAdd(&counters[COUNTER_NODE_TESTS], (unsigned long long)hc.node_tests);
