@@ -178,6 +178,7 @@ RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill,
 template <typename R>
 RRT_DEV void leaf_test_words(const SceneView<R>& sv, uint4 q0, uint4 q1, uint4 q2, uint4 q3, V3<R> o, V3<R> d,
                              HitAcc<R>& acc) {
+#pragma clang fp contract(off)
     static_assert(sizeof(R) == 4, "leaf words are an f32 record");
     const int type = (int)q3.x, g = (int)q3.y;
     R t;
@@ -187,12 +188,13 @@ RRT_DEV void leaf_test_words(const SceneView<R>& sv, uint4 q0, uint4 q1, uint4 q
         const R f4 = __uint_as_float(q1.x), f5 = __uint_as_float(q1.y), f6 = __uint_as_float(q1.z), f7 = __uint_as_float(q1.w);
         const R f8 = __uint_as_float(q2.x), f9 = __uint_as_float(q2.y), f10 = __uint_as_float(q2.z), f11 = __uint_as_float(q2.w);
         const R best_t = Num<R>::tmax();
-        R nd = f0 * d.x + f1 * d.y + f2 * d.z;
-        R no = f3 - ((f0 * o.x + f1 * o.y) + f2 * o.z);
+        R nd, no;
+        plane_nd_no<R, R>(f0, f1, f2, f3, o, d, nd, no);
         t = no * Num<R>::rcp(nd);
-        V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-        R a = ((f4 * P.x + f5 * P.y) + f6 * P.z) + f7;
-        R b = ((f8 * P.x + f9 * P.y) + f10 * P.z) + f11;
+        R px, py, pz;
+        plane_point<R, R>(t, o, d, px, py, pz);
+        R a = plane_coeff<R>(f4, f5, f6, f7, px, py, pz);
+        R b = plane_coeff<R>(f8, f9, f10, f11, px, py, pz);
         R det_ok = Num<R>::abs(nd) - Num<R>::eps();
         if (type == PRIM_PGRAM) {
             R h = min3(R(0.5) - Num<R>::abs(a), R(0.5) - Num<R>::abs(b), det_ok);

@@ -297,21 +297,104 @@ RRT_DEV R headroom(R best_t, R t) {
     return best_t - t;
 }
 
+// The arithmetic of the plane-form tests, written ONCE with every rounding spelled out (explicit fused multiply-adds,
+// contraction off for the rest) and used by the wave-uniform scan (prim_test_as), the packed pair scan (scan_run_pairs,
+// T = two records side by side) and the tree's leaves (leaf_test_words): the scan and the tree must give a primitive the
+// same t and the same verdict bit for bit (the tie rule compares distances for equality), and that must not depend on
+// which products the compiler chooses to fuse at which site.
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+RRT_DEV float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RRT_DEV double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+RRT_DEV float2_t fma_r(float2_t a, float2_t b, float2_t c) { return __builtin_elementwise_fma(a, b, c); }
+RRT_DEV double2_t fma_r(double2_t a, double2_t b, double2_t c) { return __builtin_elementwise_fma(a, b, c); }
+
+RRT_DEV void sqrt_each(float x, float& r) { r = Num<float>::sqrt(x); }
+RRT_DEV void sqrt_each(double x, double& r) { r = Num<double>::sqrt(x); }
+RRT_DEV void sqrt_each(float2_t x, float2_t& r) { r.x = Num<float>::sqrt(x.x); r.y = Num<float>::sqrt(x.y); }
+RRT_DEV void sqrt_each(double2_t x, double2_t& r) { r.x = Num<double>::sqrt(x.x); r.y = Num<double>::sqrt(x.y); }
+RRT_DEV void rcp_each(float x, float& r) { r = Num<float>::rcp(x); }
+RRT_DEV void rcp_each(double x, double& r) { r = Num<double>::rcp(x); }
+RRT_DEV void rcp_each(float2_t x, float2_t& r) { r.x = Num<float>::rcp(x.x); r.y = Num<float>::rcp(x.y); }
+RRT_DEV void rcp_each(double2_t x, double2_t& r) { r.x = Num<double>::rcp(x.x); r.y = Num<double>::rcp(x.y); }
+// out = a < limit ? yes : no, per component
+RRT_DEV void select_lt(float a, float limit, float yes, float no, float& out) { out = a < limit ? yes : no; }
+RRT_DEV void select_lt(double a, double limit, double yes, double no, double& out) { out = a < limit ? yes : no; }
+RRT_DEV void select_lt(float2_t a, float limit, float2_t yes, float2_t no, float2_t& out) {
+    out.x = a.x < limit ? yes.x : no.x;
+    out.y = a.y < limit ? yes.y : no.y;
+}
+RRT_DEV void select_lt(double2_t a, double limit, double2_t yes, double2_t no, double2_t& out) {
+    out.x = a.x < limit ? yes.x : no.x;
+    out.y = a.y < limit ? yes.y : no.y;
+}
+
+// c0 x + c1 y + c2 z = fma(c2, z, fma(c1, y, c0 x)); T = R or two records side by side, the vector is per ray
+template <typename T, typename R>
+RRT_DEV T dot3_r(T c0, T c1, T c2, R x, R y, R z) {
+#pragma clang fp contract(off)
+    return fma_r(c2, (T)(z), fma_r(c1, (T)(y), c0 * (T)(x)));
+}
+
+// n . d and n . v0 - n . o of the plane (n, k)
+template <typename T, typename R>
+RRT_DEV void plane_nd_no(T n0, T n1, T n2, T k, V3<R> o, V3<R> d, T& nd, T& no) {
+#pragma clang fp contract(off)
+    nd = dot3_r<T, R>(n0, n1, n2, d.x, d.y, d.z);
+    no = k - dot3_r<T, R>(n0, n1, n2, o.x, o.y, o.z);
+}
+
+// the hit point P = o + t d and one coefficient row:  (r0, r1, r2) . P + r3
+template <typename T, typename R>
+RRT_DEV void plane_point(T t, V3<R> o, V3<R> d, T& px, T& py, T& pz) {
+    px = fma_r(t, (T)(d.x), (T)(o.x));
+    py = fma_r(t, (T)(d.y), (T)(o.y));
+    pz = fma_r(t, (T)(d.z), (T)(o.z));
+}
+template <typename T>
+RRT_DEV T plane_coeff(T r0, T r1, T r2, T r3, T px, T py, T pz) {
+#pragma clang fp contract(off)
+    return fma_r(r2, pz, fma_r(r1, py, r0 * px)) + r3;
+}
+
+// The sphere test up to the choice of the root (src/shapes/sphere.rs:58-96): x = r^2 - d2 (negative: the ray misses),
+// d2 = squared distance of the centre from the ray, t0 = the root the reference reports.
+template <typename T, typename R>
+RRT_DEV void sphere_roots(T cx, T cy, T cz, T r2, V3<R> o, V3<R> d, T& t0, T& x, T& d2) {
+#pragma clang fp contract(off)
+    const T lx = cx - (T)(o.x), ly = cy - (T)(o.y), lz = cz - (T)(o.z);
+    const T t_ca = dot3_r<T, R>(lx, ly, lz, d.x, d.y, d.z);
+    if (sizeof(R) == 4) {
+        // |l - t_ca d|^2 equals |l|^2 - t_ca^2 for unit d; formed this way the
+        // difference of two large squares is never taken, which in f32 would
+        // lose the silhouette of a small sphere seen from far away
+        const T qx = fma_r(-t_ca, (T)(d.x), lx), qy = fma_r(-t_ca, (T)(d.y), ly), qz = fma_r(-t_ca, (T)(d.z), lz);
+        d2 = fma_r(qz, qz, fma_r(qy, qy, qx * qx));
+    } else {
+        d2 = fma_r(-t_ca, t_ca, fma_r(lz, lz, fma_r(ly, ly, lx * lx)));
+    }
+    x = r2 - d2;                    // r^2 - d2 >= 0 <=> d2 <= r^2
+    T t_hc;                         // NaN when x < 0; the x term then rejects
+    sqrt_each(x, t_hc);
+    const T ta = t_ca - t_hc, tb = t_ca + t_hc;
+    select_lt(ta, Num<R>::tmin(), tb, ta, t0);  // t0 < t_min ? t1 : t0
+}
+
 // TYPE is a compile-time constant in the run loops of the linear scan (no per-primitive
 // dispatch) and a per-lane value in tree leaves.
 template <typename R, int TYPE>
 RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
     const R RRT_CONSTANT* f = p->f;
     if (TYPE >= PRIM_TRIANGLE) {
-        // (the order of operations is the one of scan_run_pairs and leaf_test_words: a primitive gets
-        // the same t and the same verdict from the wave-uniform scan, the packed pair scan and a tree leaf)
-        R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-        R no = f[3] - ((f[0] * o.x + f[1] * o.y) + f[2] * o.z);
+#pragma clang fp contract(off)
+        R nd, no;
+        plane_nd_no<R, R>(f[0], f[1], f[2], f[3], o, d, nd, no);
         R t = no * Num<R>::rcp(nd);
         t_out = t;
-        V3<R> P = mk<R>(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);
-        R a = ((f[4] * P.x + f[5] * P.y) + f[6] * P.z) + f[7];
-        R b = ((f[8] * P.x + f[9] * P.y) + f[10] * P.z) + f[11];
+        R px, py, pz;
+        plane_point<R, R>(t, o, d, px, py, pz);
+        R a = plane_coeff<R>(f[4], f[5], f[6], f[7], px, py, pz);
+        R b = plane_coeff<R>(f[8], f[9], f[10], f[11], px, py, pz);
         R det_ok = Num<R>::abs(nd) - Num<R>::eps();
         if (TYPE == PRIM_PGRAM) {
             // parallelogram: alpha' = 1 - alpha and beta' = 1 - beta, so the two-triangle
@@ -325,12 +408,13 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
             // e21.  For a planar quad it is the point P; the loader admits quads bent by up to 2.5 degrees
             // (quadrilateral.rs:23-33) and a Quadrilateral object is not checked at all (quadrilateral.rs:204-216),
             // and there the two points differ.  The distance stays the first plane's (quadrilateral.rs:114).
-            R nd2 = f[20] * d.x + f[21] * d.y + f[22] * d.z;
-            R no2 = f[23] - ((f[20] * o.x + f[21] * o.y) + f[22] * o.z);
+            R nd2, no2;
+            plane_nd_no<R, R>(f[20], f[21], f[22], f[23], o, d, nd2, no2);
             R t2 = no2 * Num<R>::rcp(nd2);
-            V3<R> P2 = mk<R>(o.x + t2 * d.x, o.y + t2 * d.y, o.z + t2 * d.z);
-            R a2 = ((f[12] * P2.x + f[13] * P2.y) + f[14] * P2.z) + f[15];
-            R b2 = ((f[16] * P2.x + f[17] * P2.y) + f[18] * P2.z) + f[19];
+            R qx, qy, qz;
+            plane_point<R, R>(t2, o, d, qx, qy, qz);
+            R a2 = plane_coeff<R>(f[12], f[13], f[14], f[15], qx, qy, qz);
+            R b2 = plane_coeff<R>(f[16], f[17], f[18], f[19], qx, qy, qz);
             R second = min3(a2, b2, Num<R>::abs(nd2) - Num<R>::eps());  // the (v2, v3, v1) corner
             R inside = fmax(R(1) - (a + b), second);                      // alpha + beta <= 1, or that corner
             R h = min3(min3(a, b, inside), det_ok, t - Num<R>::tmin());
@@ -341,32 +425,20 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
         return (h >= R(0)) && (fmin(t - Num<R>::tmin(), headroom(best_t, t)) > R(0));
     }
     if (TYPE == PRIM_SPHERE) {  // src/shapes/sphere.rs:58-96
-        V3<R> l = mk<R>(f[0] - o.x, f[1] - o.y, f[2] - o.z);
-        R t_ca = dot(l, d);
-        R d2;
-        if (sizeof(R) == 4) {
-            // |l - t_ca d|^2 equals |l|^2 - t_ca^2 for unit d; formed this way the
-            // difference of two large squares is never taken, which in f32 would
-            // lose the silhouette of a small sphere seen from far away
-            V3<R> perp = mk<R>(l.x - t_ca * d.x, l.y - t_ca * d.y, l.z - t_ca * d.z);
-            d2 = dot(perp, perp);
-        } else {
-            d2 = dot(l, l) - t_ca * t_ca;
-        }
-        R x = f[4] - d2;                 // r^2 - d2 >= 0 <=> d2 <= r^2
-        R t_hc = Num<R>::sqrt(x);        // NaN when x < 0; the x term then rejects
-        R t0 = t_ca - t_hc;
-        R t1 = t_ca + t_hc;
-        if (t0 < Num<R>::tmin()) t0 = t1;
+        R t0, x, d2;
+        sphere_roots<R, R>(f[0], f[1], f[2], f[4], o, d, t0, x, d2);
         t_out = t0;
         return min3(fmin(x, d2), t0 - Num<R>::tmin(), headroom(best_t, t0)) >= R(0);
     }
     // plane, src/shapes/plane.rs:25-44
-    R nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-    R no = f[3] - ((f[0] * o.x + f[1] * o.y) + f[2] * o.z);
-    R t = no * Num<R>::rcp(nd);
-    t_out = t;
-    return min3(Num<R>::abs(nd) - Num<R>::eps(), t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
+    {
+#pragma clang fp contract(off)
+        R nd, no;
+        plane_nd_no<R, R>(f[0], f[1], f[2], f[3], o, d, nd, no);
+        R t = no * Num<R>::rcp(nd);
+        t_out = t;
+        return min3(Num<R>::abs(nd) - Num<R>::eps(), t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
+    }
 }
 
 template <typename R>
@@ -405,28 +477,29 @@ RRT_DEV void scan_run(const PrimRec<R> RRT_CONSTANT* prims, int first, int count
 template <typename R, int TYPE>
 RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int count, V3<R> o, V3<R> d,
                             R& best_t, int& best_g) {
+#pragma clang fp contract(off)
     typedef R R2 __attribute__((ext_vector_type(2)));
     const int n_pairs = (count + 1) >> 1;
     for (int k = 0; k < n_pairs; ++k) {
         const R2 RRT_CONSTANT* f = reinterpret_cast<const R2 RRT_CONSTANT*>(pairs[k].g);
-        // (every packed operation below reads at most one scalar register pair: the constant terms
-        //  f[3], f[7], f[11] enter through an add of their own, not as the addend of an FMA whose
-        //  multiplicand is a scalar pair too, which would cost a move into vector registers each)
-        R2 nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-        R2 no = f[3] - ((f[0] * o.x + f[1] * o.y) + f[2] * o.z);
+        // (every packed operation reads at most one scalar register pair: the constant terms f[3], f[7], f[11]
+        //  enter through an add of their own, not as the addend of an FMA whose multiplicand is a scalar pair
+        //  too, which would cost a move into vector registers each)
+        R2 nd, no;
+        plane_nd_no<R2, R>(f[0], f[1], f[2], f[3], o, d, nd, no);
         R2 rc;
-        rc.x = Num<R>::rcp(nd.x);
-        rc.y = Num<R>::rcp(nd.y);
+        rcp_each(nd, rc);
         R2 t = no * rc;
-        R2 px = o.x + t * d.x, py = o.y + t * d.y, pz = o.z + t * d.z;
-        R2 a = ((f[4] * px + f[5] * py) + f[6] * pz) + f[7];
-        R2 b = ((f[8] * px + f[9] * py) + f[10] * pz) + f[11];
+        R2 px, py, pz;
+        plane_point<R2, R>(t, o, d, px, py, pz);
+        R2 a = plane_coeff<R2>(f[4], f[5], f[6], f[7], px, py, pz);
+        R2 b = plane_coeff<R2>(f[8], f[9], f[10], f[11], px, py, pz);
         R2 tm = t - Num<R>::tmin();
         if (TYPE == PRIM_PGRAM) {
             // |a| <= 1/2 <=> 1/4 - a^2 >= 0 exactly (the square of the f32/f64 next to 1/2 rounds to the
             // proper side of 1/4), and the square form is one packed FMA for both records
-            R2 qa = R(0.25) - a * a;
-            R2 qb = R(0.25) - b * b;
+            R2 qa = fma_r(-a, a, (R2)(R(0.25)));
+            R2 qb = fma_r(-b, b, (R2)(R(0.25)));
             R h0 = min3((R)qa.x, (R)qb.x, Num<R>::abs(nd.x) - Num<R>::eps());
             const bool ok0 = min3(h0, tm.x, headroom(best_t, (R)t.x)) >= R(0);
             best_t = ok0 ? t.x : best_t;
@@ -456,16 +529,16 @@ RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int
 template <typename R, int TYPE>
 RRT_DEV void scan_run_pairs_round(const PairRec<R> RRT_CONSTANT* pairs, int first, int count, V3<R> o, V3<R> d,
                                   R& best_t, int& best_g) {
+#pragma clang fp contract(off)
     typedef R R2 __attribute__((ext_vector_type(2)));
     const int n_pairs = (count + 1) >> 1;
     for (int k = 0; k < n_pairs; ++k) {
         const R2 RRT_CONSTANT* f = reinterpret_cast<const R2 RRT_CONSTANT*>(pairs[k].g);
         if (TYPE == PRIM_PLANE) {
-            R2 nd = f[0] * d.x + f[1] * d.y + f[2] * d.z;
-            R2 no = f[3] - ((f[0] * o.x + f[1] * o.y) + f[2] * o.z);
+            R2 nd, no;
+            plane_nd_no<R2, R>(f[0], f[1], f[2], f[3], o, d, nd, no);
             R2 rc;
-            rc.x = Num<R>::rcp(nd.x);
-            rc.y = Num<R>::rcp(nd.y);
+            rcp_each(nd, rc);
             R2 t = no * rc;
             R2 tm = t - Num<R>::tmin();
             const bool ok0 = min3(Num<R>::abs(nd.x) - Num<R>::eps(), (R)tm.x, headroom(best_t, (R)t.x)) >= R(0);
@@ -475,23 +548,8 @@ RRT_DEV void scan_run_pairs_round(const PairRec<R> RRT_CONSTANT* pairs, int firs
             best_t = ok1 ? t.y : best_t;
             best_g = ok1 ? first + 2 * k + 1 : best_g;
         } else {  // PRIM_SPHERE
-            R2 lx = f[0] - o.x, ly = f[1] - o.y, lz = f[2] - o.z;
-            R2 t_ca = lx * d.x + ly * d.y + lz * d.z;
-            R2 d2;
-            if (sizeof(R) == 4) {
-                R2 qx = lx - t_ca * d.x, qy = ly - t_ca * d.y, qz = lz - t_ca * d.z;
-                d2 = qx * qx + qy * qy + qz * qz;
-            } else {
-                d2 = (lx * lx + ly * ly + lz * lz) - t_ca * t_ca;
-            }
-            R2 x = f[4] - d2;
-            R2 t_hc;
-            t_hc.x = Num<R>::sqrt(x.x);
-            t_hc.y = Num<R>::sqrt(x.y);
-            R2 t0 = t_ca - t_hc, t1 = t_ca + t_hc;
-            R2 ts;
-            ts.x = t0.x < Num<R>::tmin() ? t1.x : t0.x;
-            ts.y = t0.y < Num<R>::tmin() ? t1.y : t0.y;
+            R2 ts, x, d2;
+            sphere_roots<R2, R>(f[0], f[1], f[2], f[4], o, d, ts, x, d2);
             R2 tm = ts - Num<R>::tmin();
             // (f32: d2 is a sum of squares, so min(x, d2) >= 0 exactly when x >= 0 and the d2 term of the
             //  scalar test is dropped; f64 forms d2 as a difference and keeps it)
