@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz, packed FP32)
 PEAK_FP64_VALU_TFLOPS = 78.6   # vector FP64: one FMA per lane and clock
+PEAK_HBM_GBPS = 8000.0         # HBM3E
 
 # Algorithmic FLOPs, counted from the reference's arithmetic as written
 # (1 per add/sub/mul/div/sqrt, FMA = 2, dead code excluded).
@@ -394,6 +395,10 @@ def run_rank(args):
                 out["roofline"]["tree_record_traffic_GBps"] = steps * 64 / kernel_s / 1e9
         if wavefront and kernel_s > 0:
             out["roofline"]["queue_traffic_algorithmic_GBps"] = tot["rays"] * QUEUE_BYTES_PER_RAY / kernel_s / 1e9
+        if traffic and kernel_s > 0:
+            # the competing bound: HBM-side bytes (kept PMC figure per ray) over this run's kernel time against ~8 TB/s
+            out["roofline"]["hbm_GBps"] = traffic * args.steps / kernel_s / 1e9
+            out["roofline"]["hbm_frac"] = out["roofline"]["hbm_GBps"] / PEAK_HBM_GBPS
         if world == 1 and not args.no_cpu_baseline and not plumbing:
             cw, ch, cs = cpu_side if isinstance(cpu_side, tuple) else (width, height, cpu_side)
             out["cpu_baseline"] = cpu_baseline(flat, args.workload, cw, ch, cs, usable_cpus())
