@@ -130,3 +130,32 @@ def test_cli_splits_samples_over_gpus(tmp_path):
     r = subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(tmp_path / "x.png"), "--devices", "0,7"],
                        capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r.returncode == 101 and "GPU 7" in r.stderr
+
+
+def test_cli_next_event_flag(gpu, cfg, tmp_path):
+    """`rrt --next-event` renders with rrt_render_desc.flags = RRT_RENDER_NEE: the image of the Python mirror with the same
+    flag (more closest-hit queries than the reference's estimator: the shadow rays)."""
+    from PIL import Image
+    from rustraytracer_amd import _abi
+    api, be = gpu
+    scene = os.path.join(ROOT, "configs", "cornell_box", "scene.toml")
+    rc_path = tmp_path / "r.toml"
+    rc_path.write_text(RENDER.format(sampler="Stratified", strata="x_strata = 8\ny_strata = 8", wb=""))
+    outs = {}
+    for name, extra in (("plain", []), ("nee", ["--next-event"])):
+        out, stats = tmp_path / (name + ".png"), tmp_path / (name + ".json")
+        r = subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(out), "--stats-json", str(stats), *extra],
+                           capture_output=True, text=True, timeout=120, cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+        outs[name] = (np.asarray(Image.open(out).convert("RGB")).astype(int), json.load(open(stats)))
+    assert outs["nee"][1]["rays"] > outs["plain"][1]["rays"] and outs["nee"][1]["samples"] == outs["plain"][1]["samples"]
+    rc = cfg.load_render_config(str(rc_path))
+    sc = api.Scene(cfg.load_scene(scene))
+    rgb, st = be.render_accumulate(sc, rc.render_desc(flags=_abi.RENDER_NEE))
+    ref = be.postprocess(rgb, rc.spp, rc.post_desc())
+    got = outs["nee"][0]
+    assert np.abs(got - ref.astype(int)).max() <= 1 and np.mean(got != ref) < 0.01
+    assert st["rays"] == outs["nee"][1]["rays"]
+    # (the two estimators have the same LINEAR mean, tests/test_gpu_nee.py; after tone mapping and gamma the less noisy
+    #  image is the brighter one, so the 8-bit files are not compared with each other)
+    assert got.mean() > outs["plain"][0].mean()
