@@ -503,11 +503,11 @@ RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int
             R h0 = min3((R)qa.x, (R)qb.x, Num<R>::abs(nd.x) - Num<R>::eps());
             const bool ok0 = min3(h0, tm.x, headroom(best_t, (R)t.x)) >= R(0);
             best_t = ok0 ? t.x : best_t;
-            best_g = ok0 ? first + 2 * k : best_g;
             R h1 = min3((R)qa.y, (R)qb.y, Num<R>::abs(nd.y) - Num<R>::eps());
             const bool ok1 = min3(h1, tm.y, headroom(best_t, (R)t.y)) >= R(0);
             best_t = ok1 ? t.y : best_t;
-            best_g = ok1 ? first + 2 * k + 1 : best_g;
+            // the index of the later of the two hits: one move, one add-with-carry, one select instead of two of each
+            best_g = (ok0 || ok1) ? first + 2 * k + (ok1 ? 1 : 0) : best_g;
         } else {
             // triangle: u, v >= 0 and u + v <= 1 (u <= 1 follows: the rounded sum is never below u
             // when v >= 0), and an OPEN t interval
@@ -515,11 +515,10 @@ RRT_DEV void scan_run_pairs(const PairRec<R> RRT_CONSTANT* pairs, int first, int
             R h0 = fmin(min3((R)a.x, (R)b.x, (R)rest.x), Num<R>::abs(nd.x) - Num<R>::eps());
             const bool ok0 = (h0 >= R(0)) && (fmin((R)tm.x, headroom(best_t, (R)t.x)) > R(0));
             best_t = ok0 ? t.x : best_t;
-            best_g = ok0 ? first + 2 * k : best_g;
             R h1 = fmin(min3((R)a.y, (R)b.y, (R)rest.y), Num<R>::abs(nd.y) - Num<R>::eps());
             const bool ok1 = (h1 >= R(0)) && (fmin((R)tm.y, headroom(best_t, (R)t.y)) > R(0));
             best_t = ok1 ? t.y : best_t;
-            best_g = ok1 ? first + 2 * k + 1 : best_g;
+            best_g = (ok0 || ok1) ? first + 2 * k + (ok1 ? 1 : 0) : best_g;
         }
     }
 }
@@ -543,10 +542,9 @@ RRT_DEV void scan_run_pairs_round(const PairRec<R> RRT_CONSTANT* pairs, int firs
             R2 tm = t - Num<R>::tmin();
             const bool ok0 = min3(Num<R>::abs(nd.x) - Num<R>::eps(), (R)tm.x, headroom(best_t, (R)t.x)) >= R(0);
             best_t = ok0 ? t.x : best_t;
-            best_g = ok0 ? first + 2 * k : best_g;
             const bool ok1 = min3(Num<R>::abs(nd.y) - Num<R>::eps(), (R)tm.y, headroom(best_t, (R)t.y)) >= R(0);
             best_t = ok1 ? t.y : best_t;
-            best_g = ok1 ? first + 2 * k + 1 : best_g;
+            best_g = (ok0 || ok1) ? first + 2 * k + (ok1 ? 1 : 0) : best_g;
         } else {  // PRIM_SPHERE
             R2 ts, x, d2;
             sphere_roots<R2, R>(f[0], f[1], f[2], f[4], o, d, ts, x, d2);
@@ -556,11 +554,10 @@ RRT_DEV void scan_run_pairs_round(const PairRec<R> RRT_CONSTANT* pairs, int firs
             R in0 = sizeof(R) == 4 ? (R)x.x : fmin((R)x.x, (R)d2.x);
             const bool ok0 = min3(in0, (R)tm.x, headroom(best_t, (R)ts.x)) >= R(0);
             best_t = ok0 ? ts.x : best_t;
-            best_g = ok0 ? first + 2 * k : best_g;
             R in1 = sizeof(R) == 4 ? (R)x.y : fmin((R)x.y, (R)d2.y);
             const bool ok1 = min3(in1, (R)tm.y, headroom(best_t, (R)ts.y)) >= R(0);
             best_t = ok1 ? ts.y : best_t;
-            best_g = ok1 ? first + 2 * k + 1 : best_g;
+            best_g = (ok0 || ok1) ? first + 2 * k + (ok1 ? 1 : 0) : best_g;
         }
     }
 }

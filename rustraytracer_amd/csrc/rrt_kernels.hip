@@ -77,8 +77,13 @@ constexpr int FUSED_LDS_PRIMS = 64;
 // NEE: next-event estimation (RRT_RENDER_NEE) as a separate instantiation, so that the kernels of the reference's
 // estimator carry none of it: after the hit processing a lane at a Lambertian or Phong vertex samples a light and
 // traces the shadow ray (a second closest-hit query in the same trip).
+#ifdef RRT_EXP_WAVES8
+#define RRT_FUSED_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define RRT_FUSED_OCCUPANCY
+#endif
 template <typename R, bool BVH, bool LDS_TABLES, bool NEE = false>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) RRT_FUSED_OCCUPANCY
 render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
     __shared__ ShadeRec<R> s_shade[LDS_TABLES ? FUSED_LDS_PRIMS : 1];
     __shared__ MatRec<R> s_mats[LDS_TABLES ? FUSED_LDS_PRIMS : 1];
