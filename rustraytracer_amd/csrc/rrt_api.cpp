@@ -428,12 +428,12 @@ struct DevBuf {
 // Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO, and tree scenes with more
 // primitives than kAutoWavefrontThreshold the wavefront pipeline under RRT_PIPELINE_AUTO.  Measured on
 // triangle meshes at 1024x1024 @ 256 spp (tools/gpu_crossover.py), Grays/s:
-//   primitives      92    184    382    758   1484   5854
-//   scan, fused    14.2    7.7    3.9    2.0    1.0    0.3
-//   tree, fused     9.6    8.6    8.2    7.2    6.0    5.4
-//   tree, wavefront 7.6    7.3    7.3    7.1    6.8    6.6     (1 M triangles: 4.8 against 2.6 fused)
+//   primitives       50     92    184    382    758   1484   5854  23718  99858  399426
+//   scan, fused    25.9   15.8    8.5    4.2    2.2    1.1    0.3
+//   tree, fused    15.5   13.1   11.8   10.8    9.2    8.1    7.3    5.9    5.0    4.0
+//   tree, wavefront 7.7    7.3    7.2    7.1    7.0    6.8    6.6    6.1    6.0    5.6   (1 M triangles: 5.2 against 2.3 fused)
 const size_t kAutoBvhThreshold = 160;
-const size_t kAutoWavefrontThreshold = 800;
+const size_t kAutoWavefrontThreshold = 16000;
 // Subtrees of at most this many primitives are folded into one leaf.  A traversal step costs one
 // 64-byte fetch whether it reads a node or a primitive; 2 minimises their sum on triangle meshes.
 const int kBvhLeafMax = 2;
