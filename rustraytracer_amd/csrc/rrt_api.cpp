@@ -713,6 +713,15 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc, uint64_t lanes
     rp.chunk = chunk;
     rp.n_chunks = (rp.n_samples + chunk - 1) / chunk;
     rp.n_items = (uint64_t)rp.n_chunks * n_pixels;
+    auto magic = [](uint32_t d, uint32_t& m, uint32_t& sh) {
+        if (d <= 1) { m = 0; sh = 0xffffffffu; return; }
+        uint32_t L = 0;
+        while ((1ull << L) < d) ++L;                       // ceil(log2 d) >= 1
+        m = (uint32_t)((((unsigned long long)1 << (31 + L)) + d - 1) / d);  // ceil(2^(31 + L) / d) <= 2^32 - 1 ... 2^31
+        sh = L - 1;
+    };
+    magic((uint32_t)n_pixels, rp.div_pixels_m, rp.div_pixels_s);
+    magic(rp.width, rp.div_width_m, rp.div_width_s);
     rp.inv_width = 1.0f / (float)rp.width;
     rp.inv_height = 1.0f / (float)rp.height;
     rp.inv_spp = 1.0f / (float)rp.spp;

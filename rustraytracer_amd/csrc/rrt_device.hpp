@@ -98,6 +98,11 @@ RRT_DEV V3<R> normalize(V3<R> a) {
     return a * Num<R>::rsqrt(dot(a, a));
 }
 
+// floor(n / d) for n < 2^31 with the divisor's precomputed (m, s), see RenderParams
+RRT_DEV uint32_t fast_div(uint32_t n, uint32_t m, uint32_t s) {
+    return s == 0xffffffffu ? n : (__umulhi(n, m) >> s);
+}
+
 // ---------------------------------------------------------------- RNG
 // Counter-based: every number is a hash of (seed, pixel, sample, draw index);
 // there is no generator state to carry in a queue or to advance in order.

@@ -197,6 +197,7 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
             asm volatile("" : "+s"(q));
             const uint32_t p_width = q->width, p_chunk = q->chunk, p_n_samples = q->n_samples, p_sample_begin = q->sample_begin;
             const uint32_t p_seed_lo = q->seed_lo, p_seed_hi = q->seed_hi;
+            const uint32_t dp_m = q->div_pixels_m, dp_s = q->div_pixels_s, dw_m = q->div_width_m, dw_s = q->div_width_s;
             const uint32_t n_pixels = p_width * q->height;
             const unsigned long long p_n_items = q->n_items;
             unsigned long long* p_work_counter = q->work_counter;
@@ -221,10 +222,10 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
                 uint32_t w32 = rank < avail ? pool_next + rank : fresh_base + (rank - avail);
                 if ((unsigned long long)w32 < p_n_items) {
-                    uint32_t chunk = w32 / n_pixels;
+                    uint32_t chunk = fast_div(w32, dp_m, dp_s);
                     pixel = w32 - chunk * n_pixels;
                     pixkey = pixel_key(p_seed_lo, p_seed_hi, pixel);
-                    uint32_t py = pixel / p_width;
+                    uint32_t py = fast_div(pixel, dw_m, dw_s);
                     px_c = (R)(pixel - py * p_width) + R(0.5);
                     py_c = (R)py + R(0.5);
                     uint32_t first = chunk * p_chunk;

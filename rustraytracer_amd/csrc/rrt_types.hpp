@@ -184,6 +184,11 @@ struct RenderParams {
     float inv_width, inv_height;          // 1 / width, 1 / height
     float inv_spp, inv_x_strata, inv_y_strata;
     uint32_t flags;            // RENDER_FLAG_*
+    // floor(n / d) for n < 2^31 as umulhi(n, m) >> s (m = ceil(2^(32 + s) / d), s = ceil(log2 d) - 1; s = 0xffffffff marks
+    // d = 1): the kernels divide item numbers by the pixel count and pixel numbers by the image width, and a 32-bit
+    // division by a run-time divisor is ~35 VALU instructions
+    uint32_t div_pixels_m, div_pixels_s;
+    uint32_t div_width_m, div_width_s;
     float* accum;              // width*height*3 radiance sums (atomicAdd target)
     unsigned long long* counters;  // see COUNTER_* below
     unsigned long long* work_counter;
