@@ -198,6 +198,7 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
             const uint32_t p_width = q->width, p_chunk = q->chunk, p_n_samples = q->n_samples, p_sample_begin = q->sample_begin;
             const uint32_t p_seed_lo = q->seed_lo, p_seed_hi = q->seed_hi;
             const uint32_t dp_m = q->div_pixels_m, dp_s = q->div_pixels_s, dw_m = q->div_width_m, dw_s = q->div_width_s;
+            const uint32_t p_big = q->n_big_chunks, p_small = q->small_chunk;
             const uint32_t n_pixels = p_width * q->height;
             const unsigned long long p_n_items = q->n_items;
             unsigned long long* p_work_counter = q->work_counter;
@@ -228,8 +229,9 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
                     uint32_t py = fast_div(pixel, dw_m, dw_s);
                     px_c = (R)(pixel - py * p_width) + R(0.5);
                     py_c = (R)py + R(0.5);
-                    uint32_t first = chunk * p_chunk;
-                    uint32_t last = first + p_chunk;
+                    const bool big = chunk < p_big;
+                    uint32_t first = big ? chunk * p_chunk : p_big * p_chunk + (chunk - p_big) * p_small;
+                    uint32_t last = first + (big ? p_chunk : p_small);
                     if (last > p_n_samples) last = p_n_samples;
                     s_next = p_sample_begin + first;
                     s_end = p_sample_begin + last;

@@ -177,9 +177,12 @@ struct RenderParams {
     uint32_t min_depth, max_depth;
     uint32_t sample_begin;     // first per-pixel sample index of this call
     uint32_t n_samples;        // samples per pixel traced by this call
-    uint32_t chunk;            // samples per work item
-    uint32_t n_chunks;         // work items per pixel
-    uint64_t n_items;          // n_chunks * width * height
+    // Work items of the fused kernel: per pixel n_big_chunks items of `chunk` consecutive sample indices, then the rest
+    // in items of small_chunk.  Items are numbered chunk-major (item = chunk index * pixels + pixel), so the small
+    // ones are handed out last and the lanes run dry within a small item's time of each other.
+    uint32_t chunk;
+    uint32_t n_big_chunks;
+    uint64_t n_items;          // (n_big_chunks + small chunks per pixel) * width * height < 2^31
     uint32_t seed_lo, seed_hi;
     float inv_width, inv_height;          // 1 / width, 1 / height
     float inv_spp, inv_x_strata, inv_y_strata;
@@ -189,6 +192,7 @@ struct RenderParams {
     // division by a run-time divisor is ~35 VALU instructions
     uint32_t div_pixels_m, div_pixels_s;
     uint32_t div_width_m, div_width_s;
+    uint32_t small_chunk, pad2;
     float* accum;              // width*height*3 radiance sums (atomicAdd target)
     unsigned long long* counters;  // see COUNTER_* below
     unsigned long long* work_counter;
