@@ -373,7 +373,7 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
     if (start || mode_draws(mode)) get_draw<R>(path.smp, rp, start || mode_draws_2d(mode), u2, v2);
     bool have_ray = false;
     if (start) {
-        const uint32_t py = fast_div(pixel, rp.div_width_m, rp.div_width_s);
+        const uint32_t py = pixel / rp.width;  // (a multiply-shift with two more scalar registers costs this kernel 3 %)
         const R px_c = (R)(pixel - py * rp.width) + R(0.5);
         const R py_c = (R)py + R(0.5);
         const R u = (px_c + u2) * rp.inv_width;  // src/renderer.rs:120-121
