@@ -5,6 +5,7 @@
 set -u
 TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python3 bench.py --no-cpu-baseline $*"
