@@ -22,7 +22,7 @@ Workloads (the default is the one the headline metric is quoted on):
     smallpt       configs/smallpt, 1024x768, 128x128 strata
     cornell_cube  configs/cornell_cube (Cornell box + assets/test.ply), 1024x1024, 64x64 strata
     mesh_1m       configs/mesh_1m (Cornell shell + two generated 500k-triangle meshes), 3840x2160,
-                  32x32 strata; closest hit through the GPU-built LBVH
+                  32x32 strata; closest hit through the surface-area tree
 """
 import argparse
 import json
@@ -353,7 +353,7 @@ def run_rank(args):
                             % (scene_file, width, height, xs, ys, rc.spp, lo, hi, hi - lo),
                 "pipeline": "wavefront (SoA ray/hit queues in HBM, ballot/rank compaction)" if wavefront
                 else "fused (register-resident paths, lane regeneration)",
-                "closest_hit": "GPU-built LBVH (4-wide quantised nodes)" if use_tree else "linear scan (wave-uniform)",
+                "closest_hit": "tree: binned surface-area heuristic on the host threads, 4-wide quantised nodes widened and packed on the GPU" if use_tree else "linear scan (wave-uniform)",
                 "reduce": "RCCL sum-reduce of %.1f MB fp32 accumulators to rank 0" % (D.message_bytes(width, height) / 1e6)
                 if world > 1 else "none",
                 "samples_per_step": int(all_samples / args.steps),

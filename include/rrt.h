@@ -65,16 +65,21 @@ typedef enum rrt_sampler_type { RRT_SAMPLER_RANDOM = 0, RRT_SAMPLER_STRATIFIED =
  * traces when it draws the same random numbers. */
 typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_precision;
 
-/* How closest-hit walks the primitives.  AUTO = wave-uniform linear scan for
- * scenes of up to 160 primitives (where it is the faster of the two), LBVH
- * (+ linear scan of the unbounded planes and of quads that are not planar) otherwise. */
-typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2 } rrt_accel;
+/* How closest-hit walks the primitives.  LINEAR is the reference's scan (src/scene.rs:35-47), wave-uniform.
+ * LBVH and SAH are two builders of one tree format (4-wide nodes, 8-bit child boxes; unbounded planes and quads
+ * that are not planar are scanned beside the tree), both returning the primitive and t the scan returns:
+ *   LBVH  Morton-code radix tree built on the GPU (~0.3 s per million primitives including the upload);
+ *   SAH   binned surface-area-heuristic tree built by up to 16 host threads (~0.4 s per million primitives),
+ *         about a seventh fewer traversal steps per ray.
+ * AUTO = LINEAR for scenes of up to 160 primitives (where it is the fastest), SAH otherwise.  A scene keeps every
+ * tree it was asked for (per device) until rrt_scene_destroy. */
+typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2, RRT_ACCEL_SAH = 3 } rrt_accel;
 
 /* Which kernel organisation renders.  FUSED keeps a path in registers for
  * all of its bounces and refills finished lanes with new camera samples;
  * WAVEFRONT keeps SoA ray and hit queues in HBM and compacts them after every
  * bounce (f32 only, max_depth <= 511).  AUTO: WAVEFRONT when the closest hit
- * goes through the LBVH of a scene with more than 16000 primitives and the
+ * goes through the tree of a scene with more than 16000 primitives and the
  * precision is f32, FUSED otherwise.  Both trace the same paths for the same seed. */
 typedef enum rrt_pipeline { RRT_PIPELINE_AUTO = 0, RRT_PIPELINE_FUSED = 1, RRT_PIPELINE_WAVEFRONT = 2 } rrt_pipeline;
 
@@ -155,7 +160,7 @@ typedef struct rrt_stats {
     uint64_t samples;        /* camera samples traced */
     uint64_t rays;           /* closest-hit queries = calls of Scene::intersect (src/tracers/utils.rs:36) */
     uint64_t prim_tests;     /* primitive tests executed */
-    uint64_t node_tests;     /* LBVH node (AABB pair) visits */
+    uint64_t node_tests;     /* tree node visits */
     uint64_t bounces[5];     /* scatter evaluations per rrt_material_type */
     uint64_t nonfinite;      /* samples whose radiance was NaN/Inf (src/tracers/utils.rs:78-85 only warns) */
     double kernel_ms;        /* device time of the tracing kernels (HIP events) */
@@ -203,8 +208,8 @@ int rrt_trace_primary(rrt_backend* backend, const rrt_scene* scene, uint32_t pre
  * forbid hipMalloc).  rrt_intersect allocates five staging buffers per call; this variant stages the rays and the
  * results in a fixed array that lives in the library's device image (4 MiB per GPU the library runs on, held until
  * the process ends), so it takes at most RRT_INTERSECT_STATIC_MAX_RAYS rays per call and fails with RRT_ERR_INVALID
- * beyond that.  The scene must already be resident on the backend's device (and its LBVH built, if `accel` asks for
- * the tree): one earlier rrt_intersect call with the same scene and accel does both; otherwise RRT_ERR_INVALID.
+ * beyond that.  The scene must already be resident on the backend's device (and its tree built, if `accel` asks for
+ * one): one earlier rrt_intersect call with the same scene and accel does both; otherwise RRT_ERR_INVALID.
  * Same arguments, results and kernels as rrt_intersect.  Every call on one GPU uses that GPU's one array: calls that
  * overlap on a GPU (two host threads, two backends on the same device) race and must be serialised by the caller. */
 #define RRT_INTERSECT_STATIC_MAX_RAYS 65536

@@ -18,6 +18,7 @@
 #include "../../include/rrt.h"
 #include "rrt_launch.hpp"
 #include "rrt_lbvh.hpp"
+#include "rrt_sah.hpp"
 #include "rrt_types.hpp"
 #include "rrt_wavefront.hpp"
 
@@ -188,7 +189,17 @@ struct DeviceScene {
     rrt::SceneView<double> v64{};
     rrt::LightView<float> l32{};
     rrt::LightView<double> l64{};
-    bool has_bvh = false;
+    // One tree per builder (rrt_accel): [0] the radix tree built on the GPU, [1] the surface-area tree built on the
+    // host.  The kernels read whichever select_tree() put into the views last.
+    struct Tree {
+        bool built = false;
+        const rrt::WideNode* nodes = nullptr;
+        const rrt::LeafRec<float>* leaves32 = nullptr;
+        const rrt::LeafRec<double>* leaves64 = nullptr;
+        const int32_t* bvh_prim = nullptr;
+        const int32_t* linear_prim = nullptr;
+        int32_t n_bvh_prims = 0, n_linear_prims = 0;
+    } tree[2];
     int n_unbounded_lights = 0;  // emissive planes: next-event estimation cannot sample them
     ~DeviceScene() {
         if (device >= 0) {
@@ -437,6 +448,10 @@ const size_t kAutoWavefrontThreshold = 16000;
 // Subtrees of at most this many primitives are folded into one leaf.  A traversal step costs one
 // 64-byte fetch whether it reads a node or a primitive; 2 minimises their sum on triangle meshes.
 const int kBvhLeafMax = 2;
+// The surface-area tree keeps one primitive per leaf: its boxes separate neighbouring triangles well enough that a
+// second primitive per leaf is tested in vain more often than a node step is saved (million-triangle scene, steps per
+// ray node + primitive: 1 -> 13.3 + 3.2, 2 -> 11.9 + 5.4, 3 -> 11.6 + 7.2; radix tree: 1 -> 15.9 + 3.1, 2 -> 15.4 + 3.8).
+const int kSahLeafMax = 1;
 
 float round_down(double x) {
     float f = (float)x;
@@ -447,9 +462,26 @@ float round_up(double x) {
     return (double)f < x ? std::nextafterf(f, INFINITY) : f;
 }
 
-// Builds the LBVH of a device scene on first use (shared by the f32 and f64 views: boxes are f32).
-int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
-    if (ds->has_bvh) return RRT_OK;
+// Points the scene views at one of the scene's trees.
+void select_tree(DeviceScene* ds, int kind) {
+    const DeviceScene::Tree& t = ds->tree[kind];
+    ds->v32.nodes = ds->v64.nodes = t.nodes;
+    ds->v32.leaves = t.leaves32;
+    ds->v64.leaves = t.leaves64;
+    ds->v32.bvh_prim = ds->v64.bvh_prim = t.bvh_prim;
+    ds->v32.linear_prim = ds->v64.linear_prim = t.linear_prim;
+    ds->v32.n_bvh_prims = ds->v64.n_bvh_prims = t.n_bvh_prims;
+    ds->v32.n_linear_prims = ds->v64.n_linear_prims = t.n_linear_prims;
+}
+
+// Builds a tree of a device scene on first use (shared by the f32 and f64 views: boxes are f32) and selects it.
+// kind 0: Morton-code radix tree, built on the GPU (rrt_lbvh.hip); kind 1: binned surface-area heuristic, built by
+// the host's threads (rrt_sah.hpp).  Both end in the same 4-wide quantised nodes and leaf records.
+int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) {
+    if (ds->tree[kind].built) {
+        select_tree(ds, kind);
+        return RRT_OK;
+    }
     std::vector<int32_t> bounded, unbounded;  // scan-order indices
     std::vector<float> lo, hi;
     double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -524,33 +556,42 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
     if (n == 1) {
         if ((rc = upload(ds, bounded, &d_slot, be->stream)) != RRT_OK) return rc;
     } else if (n >= 2) {
-        DevBuf dlo, dhi;
-        HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));
-        HIP_TRY(dhi.alloc(sizeof(float) * 3 * n));
-        HIP_TRY(hipMemcpyAsync(dlo.p, lo.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
-        HIP_TRY(hipMemcpyAsync(dhi.p, hi.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
         void *nodes = nullptr, *slots = nullptr;
         HIP_TRY(hipMalloc(&nodes, sizeof(rrt::WideNode) * (size_t)(n - 1)));
         ds->allocs.push_back(nodes);
         HIP_TRY(hipMalloc(&slots, sizeof(int32_t) * (size_t)n));
         ds->allocs.push_back(slots);
-        float flo[3], fhi[3];
-        for (int k = 0; k < 3; ++k) { flo[k] = round_down(slo[k]); fhi[k] = round_up(shi[k]); }
-        int leaf_max = kBvhLeafMax;
+        int leaf_max = kind == 1 ? kSahLeafMax : kBvhLeafMax;
         if (const char* e = getenv("RRT_DEBUG_LEAF_MAX")) leaf_max = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : leaf_max;  // experiments
-        HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, leaf_max, (rrt::WideNode*)nodes,
-                                (int*)slots, be->stream));
-        // sorted slot -> index among the bounded primitives -> scan-order index
-        std::vector<int32_t> map((size_t)n);
-        HIP_TRY(hipMemcpy(map.data(), slots, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+        std::vector<int32_t> map;  // sorted slot -> index among the bounded primitives
+        if (kind == 1) {
+            std::vector<rrt::BvhNode> binary;
+            const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            rrt::SahBuilder(lo.data(), hi.data(), n, leaf_max).build(binary, map, threads);
+            HIP_TRY(rrt::bvh_widen_host_tree(binary.data(), (int)binary.size(), (rrt::WideNode*)nodes, be->stream));
+        } else {
+            DevBuf dlo, dhi;
+            HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));
+            HIP_TRY(dhi.alloc(sizeof(float) * 3 * n));
+            HIP_TRY(hipMemcpyAsync(dlo.p, lo.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
+            HIP_TRY(hipMemcpyAsync(dhi.p, hi.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
+            float flo[3], fhi[3];
+            for (int k = 0; k < 3; ++k) { flo[k] = round_down(slo[k]); fhi[k] = round_up(shi[k]); }
+            HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, leaf_max, (rrt::WideNode*)nodes,
+                                    (int*)slots, be->stream));
+            map.resize((size_t)n);
+            HIP_TRY(hipMemcpy(map.data(), slots, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
+        }
+        // -> scan-order index
         for (int i = 0; i < n; ++i) {
-            if (map[i] < 0 || map[i] >= n) return fail(RRT_ERR_HIP, "LBVH build produced an invalid slot table");
+            if (map[i] < 0 || map[i] >= n) return fail(RRT_ERR_HIP, "the tree build produced an invalid slot table");
             map[i] = bounded[(size_t)map[i]];
         }
         HIP_TRY(hipMemcpy(slots, map.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
         d_nodes = (const rrt::WideNode*)nodes;
         d_slot = (const int32_t*)slots;
     }
+    DeviceScene::Tree& tree = ds->tree[kind];
     if (n >= 1) {  // leaf records in sorted-slot order, both precisions
         void *l32 = nullptr, *l64 = nullptr;
         HIP_TRY(hipMalloc(&l32, sizeof(rrt::LeafRec<float>) * (size_t)n));
@@ -559,23 +600,32 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds) {
         ds->allocs.push_back(l64);
         HIP_TRY(rrt::lbvh_pack_leaves(ds->v32.prims, d_slot, n, (rrt::LeafRec<float>*)l32, be->stream));
         HIP_TRY(rrt::lbvh_pack_leaves(ds->v64.prims, d_slot, n, (rrt::LeafRec<double>*)l64, be->stream));
-        ds->v32.leaves = (const rrt::LeafRec<float>*)l32;
-        ds->v64.leaves = (const rrt::LeafRec<double>*)l64;
+        tree.leaves32 = (const rrt::LeafRec<float>*)l32;
+        tree.leaves64 = (const rrt::LeafRec<double>*)l64;
     }
     HIP_TRY(hipStreamSynchronize(be->stream));
-    ds->v32.nodes = ds->v64.nodes = d_nodes;
-    ds->v32.bvh_prim = ds->v64.bvh_prim = d_slot;
-    ds->v32.linear_prim = ds->v64.linear_prim = d_lin;
-    ds->v32.n_bvh_prims = ds->v64.n_bvh_prims = n;
-    ds->v32.n_linear_prims = ds->v64.n_linear_prims = (int32_t)unbounded.size();
-    ds->has_bvh = true;
+    tree.nodes = d_nodes;
+    tree.bvh_prim = d_slot;
+    tree.linear_prim = d_lin;
+    tree.n_bvh_prims = n;
+    tree.n_linear_prims = (int32_t)unbounded.size();
+    tree.built = true;
+    select_tree(ds, kind);
     return RRT_OK;
 }
 
-// AUTO: tree for scenes too large for the wave-uniform scan; LBVH: always; LINEAR: never.
+// Which tree an rrt_accel value means: -1 none (linear scan), 0 radix tree, 1 surface-area tree.
+int tree_kind(const rrt_scene* sc, uint32_t accel) {
+    if (accel == RRT_ACCEL_LBVH) return 0;
+    if (accel == RRT_ACCEL_SAH) return 1;
+    return accel == RRT_ACCEL_AUTO && sc->prims.size() > kAutoBvhThreshold ? 1 : -1;
+}
+
+// AUTO: the surface-area tree for scenes too large for the wave-uniform scan; LBVH, SAH: that tree; LINEAR: none.
 int resolve_accel(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, uint32_t accel, bool* use_bvh) {
-    *use_bvh = accel == RRT_ACCEL_LBVH || (accel == RRT_ACCEL_AUTO && sc->prims.size() > kAutoBvhThreshold);
-    return *use_bvh ? ensure_bvh(be, sc, ds) : RRT_OK;
+    const int kind = tree_kind(sc, accel);
+    *use_bvh = kind >= 0;
+    return *use_bvh ? ensure_bvh(be, sc, ds, kind) : RRT_OK;
 }
 
 // How a caller's buffer is used.  Kernels write in place only into plain device memory of the backend's own GPU:
@@ -606,7 +656,7 @@ int closest_hit_call(rrt_backend* be, const rrt_scene* scene, uint32_t precision
     if (rc != RRT_OK) return rc;
     if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
     if (precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", precision);
-    if (accel > RRT_ACCEL_LBVH) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
+    if (accel > RRT_ACCEL_SAH) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
     if (n == 0) return RRT_OK;
     if (!a || !b || !object_id || !prim_id || !t) return fail(RRT_ERR_INVALID, "NULL array argument");
     if (scene->prims.empty()) {
@@ -666,7 +716,7 @@ int validate_render_desc(const rrt_render_desc* d) {
     if (d->sample_end <= d->sample_begin) return fail(RRT_ERR_INVALID, "empty sample range");
     if (d->sample_end > 0x7fffffffull) return fail(RRT_ERR_INVALID, "sample index beyond 2^31");
     if (d->precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", d->precision);
-    if (d->accel > RRT_ACCEL_LBVH) return fail(RRT_ERR_INVALID, "unknown accel %u", d->accel);
+    if (d->accel > RRT_ACCEL_SAH) return fail(RRT_ERR_INVALID, "unknown accel %u", d->accel);
     if (d->pipeline > RRT_PIPELINE_WAVEFRONT) return fail(RRT_ERR_INVALID, "unknown pipeline %u", d->pipeline);
     if (d->flags & ~(uint32_t)RRT_RENDER_NEE) return fail(RRT_ERR_INVALID, "unknown render flags 0x%x", d->flags);
     if ((d->flags & RRT_RENDER_NEE) && d->pipeline == RRT_PIPELINE_WAVEFRONT)
@@ -1005,7 +1055,7 @@ int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t preci
     if (rc != RRT_OK) return rc;
     if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
     if (precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", precision);
-    if (accel > RRT_ACCEL_LBVH) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
+    if (accel > RRT_ACCEL_SAH) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
     if (n > (size_t)RRT_INTERSECT_STATIC_MAX_RAYS)
         return fail(RRT_ERR_INVALID, "rrt_intersect_static takes at most %d rays per call, got %zu (split the batch, or use rrt_intersect)",
                     RRT_INTERSECT_STATIC_MAX_RAYS, n);
@@ -1026,9 +1076,11 @@ int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t preci
         return fail(RRT_ERR_INVALID, "rrt_intersect_static: the scene is not resident on device %d yet; make one "
                                      "rrt_intersect call with the same scene and accel first", be->device);
     DeviceScene* ds = it->second;
-    const bool use_bvh = accel == RRT_ACCEL_LBVH || (accel == RRT_ACCEL_AUTO && scene->prims.size() > kAutoBvhThreshold);
-    if (use_bvh && !ds->has_bvh)
-        return fail(RRT_ERR_INVALID, "rrt_intersect_static: the scene's LBVH is not built on device %d yet; make one "
+    const int kind = tree_kind(scene, accel);
+    const bool use_bvh = kind >= 0;
+    if (use_bvh && ds->tree[kind].built) select_tree(ds, kind);  // pointers only
+    if (use_bvh && !ds->tree[kind].built)
+        return fail(RRT_ERR_INVALID, "rrt_intersect_static: the scene's tree is not built on device %d yet; make one "
                                      "rrt_intersect call with the same scene and accel first", be->device);
     StaticRays* sp = be->device < kMaxDevices ? g_scratch_ptr[be->device] : nullptr;
     if (!sp) return fail(RRT_ERR_UNSUPPORTED, "no static scratch on device %d", be->device);

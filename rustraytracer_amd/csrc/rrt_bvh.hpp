@@ -119,11 +119,11 @@ RRT_DEV float byte_to_float(uint32_t word, int k) {  // v_cvt_f32_ubyte<k>
 }
 
 // One wide node, given as the four 16-byte words of its WideNode record: slab tests of its (up to)
-// four children, nearest child next, the others on the stack with the farthest deepest.
+// four children.  dist[k] = entry distance of child k, or +inf if the ray misses it (or the slot is empty).
 // Conservative: boxes are padded on the host, quantised outward by the builder, and the exit
 // distance is widened by a few ulps, so the only effect of rounding is an extra visit.
 template <typename R>
-RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, uint4 q0, uint4 q1, uint4 q2, uint4 q3) {
+RRT_DEV void node_children(const TreeWalk<R>& w, uint4 q0, uint4 q1, uint4 q2, uint4 q3, R (&dist)[4], int (&child)[4]) {
     const R widen = sizeof(R) == 4 ? R(1.0000004) : R(1.0000000001);
     const R inf = Num<R>::tmax();
     // plane distance t = (org + q s - o) / d = q (s / d) + (org - o) / d: two multiplies and a subtract per
@@ -144,8 +144,6 @@ RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill,
     const uint32_t qny = ny ? q2.x : q1.y, qfy = ny ? q1.y : q2.x;
     const uint32_t qnz = nz ? q2.y : q1.z, qfz = nz ? q1.z : q2.y;
     const int link[4] = {(int)q2.z, (int)q2.w, (int)q3.x, (int)q3.y};
-    R dist[4];
-    int child[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         R2 qx, qy, qz;  // (near, far)
@@ -159,17 +157,31 @@ RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill,
         const bool hit = en <= fmin(ex, w.acc.t) && ex >= R(0) && child[k] != BVH_NO_CHILD;
         dist[k] = hit ? en : inf;
     }
+}
+
+// Nearest of the children that were hit next, the others on the stack with the farthest deepest.
+template <typename R, typename Push, typename Pop>
+RRT_DEV void node_descend(TreeWalk<R>& w, R (&dist)[4], int (&child)[4], Push push, Pop pop) {
+    const R inf = Num<R>::tmax();
     // sorting network for four keys
     order2(dist[0], child[0], dist[1], child[1]);
     order2(dist[2], child[2], dist[3], child[3]);
     order2(dist[0], child[0], dist[2], child[2]);
     order2(dist[1], child[1], dist[3], child[3]);
     order2(dist[1], child[1], dist[2], child[2]);
-    if (dist[3] < inf) walk_push(w, lds, spill, child[3]);
-    if (dist[2] < inf) walk_push(w, lds, spill, child[2]);
-    if (dist[1] < inf) walk_push(w, lds, spill, child[1]);
+    if (dist[3] < inf) push(child[3]);
+    if (dist[2] < inf) push(child[2]);
+    if (dist[1] < inf) push(child[1]);
     if (dist[0] < inf) w.node = child[0];
-    else walk_pop(w, lds, spill);
+    else pop();
+}
+
+template <typename R>
+RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, uint4 q0, uint4 q1, uint4 q2, uint4 q3) {
+    R dist[4];
+    int child[4];
+    node_children(w, q0, q1, q2, q3, dist, child);
+    node_descend(w, dist, child, [&](int c) { walk_push(w, lds, spill, c); }, [&]() { walk_pop(w, lds, spill); });
 }
 
 // One leaf primitive, given as the four 16-byte words of its LeafRec<float> record, against the ray.

@@ -9,6 +9,7 @@
 //   6. collapse_kernel subtrees of a few primitives become single leaves (slot ranges)
 //   7. widen_kernel    every binary node with its children expanded: the 4-wide nodes rays traverse
 //   8. reachable/compact the wide nodes rays can reach, packed to the front of the node array
+// Steps 7 and 8 also serve binary trees built on the host (bvh_widen_host_tree; rrt_sah.hpp).
 //
 // A binary node holds the boxes of BOTH children; child < 0 encodes a leaf, see BvhNode;
 // prim_of_slot[slot] = index into the bounds arrays.
@@ -305,6 +306,30 @@ refit_kernel(const float* __restrict__ lo, const float* __restrict__ hi, const i
     }
 }
 
+// Runs widen_greedy_kernel level by level from the root until no node is marked any more.  state: n ints.
+static hipError_t widen_greedy(const BvhNode* d_nodes, int n, WideNode* wide_tmp, int* state, int max_rounds, hipStream_t stream) {
+    int* marked = nullptr;
+    hipError_t e = hipMalloc(&marked, sizeof(int));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(state, 0, sizeof(int) * n, stream);
+    const int one = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(state, &one, sizeof(int), hipMemcpyHostToDevice, stream);
+    const dim3 block(256), grid((n + 255) / 256);
+    for (int round = 0; e == hipSuccess; ++round) {
+        int again = 0;
+        e = hipMemsetAsync(marked, 0, sizeof(int), stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(widen_greedy_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp, state, marked);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&again, marked, sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess || !again) break;
+        if (round > max_rounds) { e = hipErrorUnknown; break; }
+    }
+    (void)hipFree(marked);
+    return e;
+}
+
 hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float scene_lo[3], const float scene_hi[3],
                       int leaf_max, WideNode* d_wide, int* d_prim_of_slot, hipStream_t stream) {
     if (n < 2 || n > BVH_MAX_PRIMS || leaf_max < 1 || leaf_max > 8) return hipErrorInvalidValue;
@@ -364,25 +389,7 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
     static const bool greedy = [] { const char* e = getenv("RRT_DEBUG_WIDEN_GREEDY"); return e ? atoi(e) != 0 : true; }();  // experiments
     if (greedy) {
         int* state = range_first;  // free after the collapse
-        int* marked = nullptr;
-        LBVH_TRY(hipMalloc(&marked, sizeof(int)));
-        auto drop = [&]() { (void)hipFree(marked); };
-        e = hipMemsetAsync(state, 0, sizeof(int) * n, stream);
-        const int one = 1;
-        if (e == hipSuccess) e = hipMemcpyAsync(state, &one, sizeof(int), hipMemcpyHostToDevice, stream);
-        for (int round = 0; e == hipSuccess; ++round) {
-            int again = 0;
-            e = hipMemsetAsync(marked, 0, sizeof(int), stream);
-            if (e != hipSuccess) break;
-            hipLaunchKernelGGL(widen_greedy_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp, state, marked);
-            e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(&again, marked, sizeof(int), hipMemcpyDeviceToHost, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess || !again) break;
-            if (round > 4 * 96) { e = hipErrorUnknown; break; }  // deeper than any radix tree over 63 + 32 bits
-        }
-        drop();
-        LBVH_TRY(e);
+        LBVH_TRY(widen_greedy(d_nodes, n, wide_tmp, state, 4 * 96, stream));  // no radix tree over 63 + 32 bits is deeper
         hipLaunchKernelGGL(finished_flag_kernel, grid, block, 0, stream, state, n, flag);
         LBVH_TRY(hipGetLastError());
     } else {
@@ -403,6 +410,42 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
         }
         LBVH_TRY(rocprim::exclusive_scan(temp, scan_bytes, flag, new_index, 0, (size_t)(n - 1), rocprim::plus<int>(), stream));
     }
+    hipLaunchKernelGGL(compact_kernel, grid, block, 0, stream, wide_tmp, flag, new_index, n, d_wide);
+    LBVH_TRY(hipGetLastError());
+    LBVH_TRY(hipStreamSynchronize(stream));
+#undef LBVH_TRY
+    cleanup();
+    return hipSuccess;
+}
+
+// The wide nodes of a binary tree built on the host (rrt_sah.hpp): m binary nodes, node 0 the root.
+hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, WideNode* d_wide, hipStream_t stream) {
+    if (m < 1) return hipErrorInvalidValue;
+    const int n = m + 1;  // the kernels take the primitive count of a full binary tree
+    hipError_t e;
+    BvhNode* d_nodes = nullptr;
+    WideNode* wide_tmp = nullptr;
+    int *state = nullptr, *flag = nullptr, *new_index = nullptr;
+    void* temp = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_nodes); (void)hipFree(wide_tmp); (void)hipFree(state); (void)hipFree(flag); (void)hipFree(new_index);
+        (void)hipFree(temp);
+    };
+#define LBVH_TRY(x) do { e = (x); if (e != hipSuccess) { cleanup(); return e; } } while (0)
+    LBVH_TRY(hipMalloc(&d_nodes, sizeof(BvhNode) * (size_t)m));
+    LBVH_TRY(hipMalloc(&wide_tmp, sizeof(WideNode) * (size_t)m));
+    LBVH_TRY(hipMalloc(&state, sizeof(int) * n));
+    LBVH_TRY(hipMalloc(&flag, sizeof(int) * n));
+    LBVH_TRY(hipMalloc(&new_index, sizeof(int) * n));
+    LBVH_TRY(hipMemcpyAsync(d_nodes, h_nodes, sizeof(BvhNode) * (size_t)m, hipMemcpyHostToDevice, stream));
+    dim3 block(256), grid((n + 255) / 256);
+    LBVH_TRY(widen_greedy(d_nodes, n, wide_tmp, state, m, stream));
+    hipLaunchKernelGGL(finished_flag_kernel, grid, block, 0, stream, state, n, flag);
+    LBVH_TRY(hipGetLastError());
+    size_t scan_bytes = 0;
+    LBVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, new_index, 0, (size_t)m, rocprim::plus<int>(), stream));
+    LBVH_TRY(hipMalloc(&temp, scan_bytes ? scan_bytes : 16));
+    LBVH_TRY(rocprim::exclusive_scan(temp, scan_bytes, flag, new_index, 0, (size_t)m, rocprim::plus<int>(), stream));
     hipLaunchKernelGGL(compact_kernel, grid, block, 0, stream, wide_tmp, flag, new_index, n, d_wide);
     LBVH_TRY(hipGetLastError());
     LBVH_TRY(hipStreamSynchronize(stream));

@@ -1,0 +1,217 @@
+// Host-side top-down builder of the binary tree under the wide nodes: binned surface-area heuristic.
+// Produces what the radix-tree kernels of rrt_lbvh.hip produce (BvhNode records holding the boxes of
+// both children, leaves as slot ranges, node 0 the root), so the widening and packing kernels take
+// either tree.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <thread>
+#include <vector>
+
+#include "rrt_types.hpp"
+
+namespace rrt {
+
+struct SahBox {
+    float lo[3], hi[3];
+    void clear() { for (int a = 0; a < 3; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; } }
+    void grow(const float* l, const float* h) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); } }
+    void grow(const SahBox& b) { grow(b.lo, b.hi); }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+class SahBuilder {
+public:
+    static constexpr int BINS = 16;
+    SahBuilder(const float* lo, const float* hi, int n, int leaf_max) : lo_(lo), hi_(hi), n_(n), leaf_max_(leaf_max) {}
+
+    // nodes: at most n - 1 records, node 0 the root; prim_of_slot: n entries.  Needs n >= 2.
+    // The top of the tree is split on the calling thread down to ranges of at most `grain` primitives; those
+    // subtrees are independent jobs for `threads` threads.  Ranges, cuts and the order of the records depend
+    // on the input alone, not on the number of threads.
+    void build(std::vector<BvhNode>& nodes, std::vector<int32_t>& prim_of_slot, int threads) {
+        prim_of_slot.resize((size_t)n_);
+        for (int i = 0; i < n_; ++i) prim_of_slot[(size_t)i] = i;
+        idx_ = prim_of_slot.data();
+        nodes.clear();
+        nodes.reserve((size_t)n_);
+        nodes.emplace_back();
+        const int grain = std::max(4096, n_ / 64);
+        std::vector<Job> jobs;
+        if (n_ <= grain) jobs.push_back({0, 0, n_});
+        else expand(nodes, 0, 0, n_, grain, &jobs);
+        std::vector<std::vector<BvhNode>> local(jobs.size());
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
+                local[j].reserve((size_t)jobs[j].count);
+                local[j].emplace_back();
+                expand(local[j], 0, jobs[j].first, jobs[j].count, 0, nullptr);
+            }
+        };
+        threads = std::max(1, std::min(threads, (int)jobs.size()));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const int32_t base = (int32_t)nodes.size();  // local record k >= 1 becomes record base + k - 1
+            for (size_t k = 0; k < local[j].size(); ++k) {
+                BvhNode N = local[j][k];
+                if (N.c0 >= 0) N.c0 += base - 1;
+                if (N.c1 >= 0) N.c1 += base - 1;
+                if (k == 0) nodes[(size_t)jobs[j].id] = N;
+                else nodes.push_back(N);
+            }
+        }
+    }
+
+private:
+    const float* lo_;
+    const float* hi_;
+    int n_, leaf_max_;
+    int32_t* idx_ = nullptr;
+    struct Job { int id, first, count; };
+
+    SahBox bounds_of(int first, int count) const {
+        SahBox b;
+        b.clear();
+        for (int i = first; i < first + count; ++i) b.grow(lo_ + 3 * (size_t)idx_[i], hi_ + 3 * (size_t)idx_[i]);
+        return b;
+    }
+
+    // Small ranges: every cut of the order along every axis is tried (bins are too coarse to keep the
+    // two triangles of a mesh cell together).
+    static constexpr int SWEEP_MAX = 32;
+    int partition_sweep(int first, int count) {
+        std::pair<float, int32_t> key[SWEEP_MAX];
+        int32_t best_order[SWEEP_MAX];
+        float right_area[SWEEP_MAX];
+        float best_cost = 3.0e38f;
+        int best_nl = count / 2;
+        bool found = false;
+        for (int a = 0; a < 3; ++a) {
+            for (int i = 0; i < count; ++i) {
+                const int32_t p = idx_[first + i];
+                key[i] = {0.5f * (lo_[3 * (size_t)p + a] + hi_[3 * (size_t)p + a]), p};
+            }
+            std::sort(key, key + count);
+            SahBox acc;
+            acc.clear();
+            for (int i = count - 1; i > 0; --i) {
+                acc.grow(lo_ + 3 * (size_t)key[i].second, hi_ + 3 * (size_t)key[i].second);
+                right_area[i] = acc.half_area();
+            }
+            acc.clear();
+            for (int i = 0; i < count - 1; ++i) {
+                acc.grow(lo_ + 3 * (size_t)key[i].second, hi_ + 3 * (size_t)key[i].second);
+                const int nl = i + 1, nr = count - nl;
+                // leaves hold up to leaf_max_ primitives: a part of that size costs one box, whatever it holds
+                const float cost = acc.half_area() * (float)(nl <= leaf_max_ ? 1 : nl) + right_area[i + 1] * (float)(nr <= leaf_max_ ? 1 : nr);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_nl = nl;
+                    found = true;
+                    for (int k = 0; k < count; ++k) best_order[k] = key[k].second;
+                }
+            }
+        }
+        if (found)
+            for (int k = 0; k < count; ++k) idx_[first + k] = best_order[k];
+        return best_nl;
+    }
+
+    // Where to cut [first, first + count): returns the size of the left part (1 .. count - 1).
+    int partition(int first, int count) {
+        if (count <= SWEEP_MAX) return partition_sweep(first, count);
+        float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int i = first; i < first + count; ++i) {
+            const size_t p = (size_t)idx_[i];
+            for (int a = 0; a < 3; ++a) {
+                const float c = 0.5f * (lo_[3 * p + a] + hi_[3 * p + a]);
+                clo[a] = std::min(clo[a], c);
+                chi[a] = std::max(chi[a], c);
+            }
+        }
+        float best_cost = 3.0e38f;
+        int best_axis = -1, best_bin = 0;
+        float best_scale = 0.f;
+        float scale[3];
+        for (int a = 0; a < 3; ++a) scale[a] = chi[a] > clo[a] ? (float)BINS * (1.f - 1e-6f) / (chi[a] - clo[a]) : 0.f;
+        SahBox bin_box[3][BINS];
+        int bin_n[3][BINS];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < BINS; ++b) { bin_box[a][b].clear(); bin_n[a][b] = 0; }
+        for (int i = first; i < first + count; ++i) {
+            const size_t p = (size_t)idx_[i];
+            for (int a = 0; a < 3; ++a) {
+                int b = (int)((0.5f * (lo_[3 * p + a] + hi_[3 * p + a]) - clo[a]) * scale[a]);
+                b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                bin_box[a][b].grow(lo_ + 3 * p, hi_ + 3 * p);
+                bin_n[a][b] += 1;
+            }
+        }
+        for (int a = 0; a < 3; ++a) {
+            if (!(scale[a] > 0.f)) continue;
+            float right_area[BINS];
+            SahBox acc;
+            acc.clear();
+            for (int b = BINS - 1; b > 0; --b) {
+                if (bin_n[a][b]) acc.grow(bin_box[a][b]);
+                right_area[b] = acc.half_area();
+            }
+            acc.clear();
+            int nl = 0;
+            for (int b = 0; b < BINS - 1; ++b) {
+                if (bin_n[a][b]) acc.grow(bin_box[a][b]);
+                nl += bin_n[a][b];
+                const int nr = count - nl;
+                if (nl == 0 || nr == 0) continue;
+                const float cost = acc.half_area() * (float)nl + right_area[b + 1] * (float)nr;
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; best_scale = scale[a]; }
+            }
+        }
+        if (best_axis < 0) return count / 2;  // all centres coincide: any cut is as good
+        const int a = best_axis;
+        int32_t* mid = std::partition(idx_ + first, idx_ + first + count, [&](int32_t p) {
+            int b = (int)((0.5f * (lo_[3 * (size_t)p + a] + hi_[3 * (size_t)p + a]) - clo[a]) * best_scale);
+            b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+            return b <= best_bin;
+        });
+        const int nl = (int)(mid - (idx_ + first));
+        return (nl <= 0 || nl >= count) ? count / 2 : nl;
+    }
+
+    // Builds the subtree of out[root] over [first0, first0 + count0).  With `jobs`, ranges of at most `grain`
+    // primitives get their record in `out` but are left for later (one job each).
+    void expand(std::vector<BvhNode>& out, int root, int first0, int count0, int grain, std::vector<Job>* jobs) {
+        std::vector<Job> todo;
+        todo.push_back({root, first0, count0});
+        auto link = [&](int first, int count) -> int32_t {
+            if (count <= leaf_max_) return ~(first | ((count - 1) << BVH_SLOT_BITS));
+            const int id = (int)out.size();
+            out.emplace_back();
+            if (jobs && count <= grain) jobs->push_back({id, first, count});
+            else todo.push_back({id, first, count});
+            return id;
+        };
+        while (!todo.empty()) {
+            const Job j = todo.back();
+            todo.pop_back();
+            const int nl = partition(j.first, j.count);
+            const SahBox bl = bounds_of(j.first, nl), br = bounds_of(j.first + nl, j.count - nl);
+            const int32_t c0 = link(j.first, nl), c1 = link(j.first + nl, j.count - nl);
+            BvhNode& N = out[(size_t)j.id];
+            for (int a = 0; a < 3; ++a) { N.lo0[a] = bl.lo[a]; N.hi0[a] = bl.hi[a]; N.lo1[a] = br.lo[a]; N.hi1[a] = br.hi[a]; }
+            N.c0 = c0;
+            N.c1 = c1;
+            N.pad0 = N.pad1 = 0;
+        }
+    }
+};
+
+}  // namespace rrt

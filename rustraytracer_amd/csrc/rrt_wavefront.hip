@@ -155,6 +155,9 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
     HitCounters hc{0, 0};
     uint32_t mine = 0;
     bool have = false;
+#ifdef RRT_EXP_TREE_STATS  // experiment: one wave in 509 blocks prints how its lanes were occupied (lanes with work, lanes at a node, refills)
+    uint32_t st_trips = 0, st_work = 0, st_node = 0, st_refill = 0, st_refill_idle = 0, st_mixed = 0;
+#endif
 
     for (;;) {
         const bool idle = w.node == BVH_DONE;
@@ -187,7 +190,20 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                 }
             }
             if (__ballot(w.node != BVH_DONE) == 0ull) break;
+#ifdef RRT_EXP_TREE_STATS
+            st_refill += 1;
+            st_refill_idle += n_idle;
+#endif
         }
+#ifdef RRT_EXP_TREE_STATS
+        {
+            const uint32_t nw = (uint32_t)__popcll(__ballot(w.node != BVH_DONE)), nn = (uint32_t)__popcll(__ballot(w.node >= 0));
+            st_trips += 1;
+            st_work += nw;
+            st_node += nn;
+            st_mixed += (nn > 0 && nn < nw) ? 1u : 0u;
+        }
+#endif
         // One step for every lane that has work: a wide node or ONE leaf primitive.  Both records are
         // 64 bytes, so all lanes share the same four 16-byte loads and only the arithmetic diverges;
         // no lane waits for the others to reach the same kind of record.
@@ -218,6 +234,10 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
             }
         }
     }
+#ifdef RRT_EXP_TREE_STATS
+    if (blockIdx.x % 509u == 3u && threadIdx.x == 64 && n_in > 40000000u)
+        printf("TREESTAT trips %u work %u node %u refills %u refill_idle %u mixed %u\n", st_trips, st_work, st_node, st_refill, st_refill_idle, st_mixed);
+#endif
     for (int sh = 32; sh > 0; sh >>= 1) {
         hc.prim_tests += __shfl_xor(hc.prim_tests, sh);
         hc.node_tests += __shfl_xor(hc.node_tests, sh);

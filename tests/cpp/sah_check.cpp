@@ -1,0 +1,145 @@
+// Host-only check of the surface-area tree builder (rustraytracer_amd/csrc/rrt_sah.hpp): structural
+// invariants on several inputs, and the same tree from one thread and from several.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "rrt_sah.hpp"
+
+using rrt::BvhNode;
+
+static int failures = 0;
+#define CHECK(c, ...) do { if (!(c)) { std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); ++failures; } } while (0)
+
+struct Input {
+    std::vector<float> lo, hi;
+    int n() const { return (int)lo.size() / 3; }
+    void add(const float* c, const float* half) {
+        for (int a = 0; a < 3; ++a) { lo.push_back(c[a] - half[a]); hi.push_back(c[a] + half[a]); }
+    }
+};
+
+static Input random_boxes(int n, unsigned seed, float spread) {
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<float> u(-1.f, 1.f), s(0.f, 0.05f);
+    Input in;
+    for (int i = 0; i < n; ++i) {
+        const float c[3] = {spread * u(rng), spread * u(rng), spread * u(rng)}, h[3] = {s(rng), s(rng), s(rng)};
+        in.add(c, h);
+    }
+    return in;
+}
+
+static Input grid_cells(int g) {  // two flat triangles' boxes per cell of a height field
+    Input in;
+    for (int j = 0; j < g; ++j)
+        for (int i = 0; i < g; ++i)
+            for (int t = 0; t < 2; ++t) {
+                const float c[3] = {(i + 0.5f) / g, (j + 0.5f) / g, 0.1f * std::sin(9.f * i / g) * std::cos(7.f * j / g)};
+                const float h[3] = {0.5f / g, 0.5f / g, 0.01f};
+                in.add(c, h);
+            }
+    return in;
+}
+
+// Walks the tree; every slot must be covered exactly once, every child box must contain its primitives' boxes.
+static void check_tree(const char* name, const Input& in, int leaf_max, const std::vector<BvhNode>& nodes,
+                       const std::vector<int32_t>& order) {
+    const int n = in.n();
+    CHECK((int)order.size() == n, "%s: order size", name);
+    CHECK((int)nodes.size() <= n - 1 && !nodes.empty(), "%s: %zu nodes for %d primitives", name, nodes.size(), n);
+    std::vector<int> seen_prim((size_t)n, 0), seen_slot((size_t)n, 0), seen_node(nodes.size(), 0);
+    for (int32_t p : order) {
+        CHECK(p >= 0 && p < n, "%s: order entry %d", name, p);
+        if (p >= 0 && p < n) seen_prim[(size_t)p] += 1;
+    }
+    for (int i = 0; i < n; ++i) CHECK(seen_prim[(size_t)i] == 1, "%s: primitive %d appears %d times", name, i, seen_prim[(size_t)i]);
+    struct Ret { float lo[3], hi[3]; int first, count; };
+    // iterative post-order: returns the box and slot range of every subtree
+    std::vector<int> stack{0};
+    std::vector<Ret> ret(nodes.size());
+    std::vector<char> expanded(nodes.size(), 0);
+    auto leaf = [&](int32_t link, Ret& r) {
+        const int v = ~link, first = v & rrt::BVH_SLOT_MASK, count = (v >> rrt::BVH_SLOT_BITS) + 1;
+        CHECK(count >= 1 && count <= leaf_max && first >= 0 && first + count <= n, "%s: leaf [%d, +%d)", name, first, count);
+        r.first = first;
+        r.count = count;
+        for (int a = 0; a < 3; ++a) { r.lo[a] = 3e38f; r.hi[a] = -3e38f; }
+        for (int s = first; s < first + count && s < n; ++s) {
+            seen_slot[(size_t)s] += 1;
+            const size_t p = (size_t)order[(size_t)s];
+            for (int a = 0; a < 3; ++a) { r.lo[a] = std::fmin(r.lo[a], in.lo[3 * p + a]); r.hi[a] = std::fmax(r.hi[a], in.hi[3 * p + a]); }
+        }
+    };
+    while (!stack.empty()) {
+        const int id = stack.back();
+        const BvhNode& N = nodes[(size_t)id];
+        if (!expanded[(size_t)id]) {
+            expanded[(size_t)id] = 1;
+            seen_node[(size_t)id] += 1;
+            for (int32_t c : {N.c0, N.c1})
+                if (c >= 0) {
+                    CHECK(c > 0 && c < (int)nodes.size(), "%s: child link %d", name, c);
+                    if (c > 0 && c < (int)nodes.size() && !expanded[(size_t)c]) stack.push_back(c);
+                }
+            continue;
+        }
+        stack.pop_back();
+        Ret r0, r1;
+        if (N.c0 >= 0) r0 = ret[(size_t)N.c0]; else leaf(N.c0, r0);
+        if (N.c1 >= 0) r1 = ret[(size_t)N.c1]; else leaf(N.c1, r1);
+        CHECK(r0.first + r0.count == r1.first, "%s: node %d children are not adjacent slot ranges", name, id);
+        for (int a = 0; a < 3; ++a) {
+            CHECK(N.lo0[a] <= r0.lo[a] && N.hi0[a] >= r0.hi[a], "%s: node %d box 0 axis %d", name, id, a);
+            CHECK(N.lo1[a] <= r1.lo[a] && N.hi1[a] >= r1.hi[a], "%s: node %d box 1 axis %d", name, id, a);
+        }
+        Ret& r = ret[(size_t)id];
+        r.first = r0.first;
+        r.count = r0.count + r1.count;
+        for (int a = 0; a < 3; ++a) { r.lo[a] = std::fmin(r0.lo[a], r1.lo[a]); r.hi[a] = std::fmax(r0.hi[a], r1.hi[a]); }
+    }
+    CHECK(ret[0].first == 0 && ret[0].count == n, "%s: the root covers [%d, +%d)", name, ret[0].first, ret[0].count);
+    for (int s = 0; s < n; ++s) CHECK(seen_slot[(size_t)s] == 1, "%s: slot %d in %d leaves", name, s, seen_slot[(size_t)s]);
+    for (size_t i = 0; i < nodes.size(); ++i) CHECK(seen_node[i] == 1, "%s: node %zu reached %d times", name, i, seen_node[i]);
+}
+
+static double sah_cost(const std::vector<BvhNode>& nodes) {  // sum of child box areas over the root area
+    double sum = 0;
+    auto area = [](const float* l, const float* h) { const double x = h[0] - l[0], y = h[1] - l[1], z = h[2] - l[2]; return x * y + y * z + z * x; };
+    for (const BvhNode& N : nodes) sum += area(N.lo0, N.hi0) + area(N.lo1, N.hi1);
+    return sum;
+}
+
+static void run(const char* name, const Input& in, int leaf_max) {
+    std::vector<BvhNode> a, b;
+    std::vector<int32_t> oa, ob;
+    rrt::SahBuilder(in.lo.data(), in.hi.data(), in.n(), leaf_max).build(a, oa, 1);
+    rrt::SahBuilder(in.lo.data(), in.hi.data(), in.n(), leaf_max).build(b, ob, 5);
+    check_tree(name, in, leaf_max, a, oa);
+    CHECK(a.size() == b.size() && oa == ob && std::memcmp(a.data(), b.data(), a.size() * sizeof(BvhNode)) == 0,
+          "%s: one thread and five threads built different trees", name);
+    std::printf("%-22s n %7d leaf_max %d: %7zu nodes, child area sum %.4g\n", name, in.n(), leaf_max, a.size(), sah_cost(a));
+}
+
+int main() {
+    for (int leaf_max : {1, 2, 4}) {
+        run("two", random_boxes(2, 1, 1.f), leaf_max);
+        run("three", random_boxes(3, 2, 1.f), leaf_max);
+        run("random 1000", random_boxes(1000, 3, 1.f), leaf_max);
+        run("random 300000", random_boxes(300000, 4, 10.f), leaf_max);
+        run("same centre 5000", random_boxes(5000, 5, 0.f), leaf_max);
+        run("grid 200x200x2", grid_cells(200), leaf_max);
+    }
+    {   // every box identical: no cut is better than another, the build must still end
+        Input in;
+        const float c[3] = {1, 2, 3}, h[3] = {0.5f, 0.5f, 0.5f};
+        for (int i = 0; i < 777; ++i) in.add(c, h);
+        run("identical 777", in, 2);
+    }
+    if (failures) { std::printf("%d failures\n", failures); return 1; }
+    std::printf("ok\n");
+    return 0;
+}

@@ -1,5 +1,6 @@
-"""GPU-built LBVH: it must return the same closest hit as the linear scan (ids AND distance, bit for bit,
-in both precisions), including the reference's tie rule, with unbounded planes kept beside the tree."""
+"""The two trees (the radix tree built on the GPU, the surface-area tree built on the host): either must return the
+same closest hit as the linear scan (ids AND distance, bit for bit, in both precisions), including the reference's
+tie rule, with unbounded planes kept beside the tree."""
 import os
 import sys
 
@@ -14,6 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import make_mesh  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+
+TREES = (_abi.ACCEL_LBVH, _abi.ACCEL_SAH)
 
 
 def mesh_scene(n_tri, seed=2, with_quads=False):
@@ -73,8 +76,9 @@ def test_lbvh_equals_linear_scan(gpu, O, cfg, scenes, cornell, name):
     ref = O.intersect(flat, o, d)
     for prec in (api.PRECISION_F64, api.PRECISION_F32):
         lin = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LINEAR)
-        bvh = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LBVH)
-        assert _same(lin, bvh), f"{name} prec {prec}: tree and scan disagree"
+        for tree in TREES:
+            bvh = be.intersect(sc, o, d, precision=prec, accel=tree)
+            assert _same(lin, bvh), f"{name} prec {prec} tree {tree}: tree and scan disagree"
     bvh64 = be.intersect(sc, o, d, precision=api.PRECISION_F64, accel=api.ACCEL_LBVH)
     bad = (bvh64[0] != ref[0]) | (bvh64[1] != ref[1])
     with np.errstate(invalid="ignore"):
@@ -96,7 +100,7 @@ def test_lbvh_tie_rule(gpu):
     for prims, winner in cases:
         sc = api.Scene(S.make_scene(prims, mats))
         for prec in (api.PRECISION_F32, api.PRECISION_F64):
-            for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH):
+            for accel in (api.ACCEL_LINEAR,) + TREES:
                 assert be.intersect(sc, o, d, precision=prec, accel=accel)[0][0] == winner, (prims, accel)
 
 
@@ -130,10 +134,11 @@ def test_render_with_lbvh_matches_linear(gpu, cfg, cornell):
     sc = api.Scene(flat)
     rc = cfg.stratified_config(48, 48, 8, 8, seed=2)
     a, sa = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LINEAR))
-    b, sb = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LBVH))
-    assert sa["rays"] == sb["rays"] and sa["bounces"] == sb["bounces"]
-    assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
-    assert sb["node_tests"] > 0 and sb["prim_tests"] < sa["prim_tests"]
+    for tree in TREES:
+        b, sb = be.render_accumulate(sc, rc.render_desc(accel=tree))
+        assert sa["rays"] == sb["rays"] and sa["bounces"] == sb["bounces"]
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-5)
+        assert sb["node_tests"] > 0 and sb["prim_tests"] < sa["prim_tests"]
     assert sa["bounces"][2] > 0  # the Phong cube is hit
 
 
@@ -149,8 +154,9 @@ def test_degenerate_trees(gpu):
                           ([(1, 0, 0, [0, 0, -3, 0, 0, 1]), (2, 1, 0, tri), (0, 2, 0, [0, 5, 0, 1.0])], [1, 2])):
         sc = api.Scene(S.make_scene(prims, mats))
         for prec in (api.PRECISION_F32, api.PRECISION_F64):
-            got = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LBVH)
-            assert list(got[0]) == expect, (prims, got)
+            for tree in TREES:
+                got = be.intersect(sc, o, d, precision=prec, accel=tree)
+                assert list(got[0]) == expect, (prims, got, tree)
 
 
 def _rays(n, seed):
@@ -195,24 +201,26 @@ def test_lbvh_edge_cases(gpu, case):
     o = o + shift
     for prec in (api.PRECISION_F64, api.PRECISION_F32):
         lin = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LINEAR)
-        bvh = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LBVH)
-        assert _same(lin, bvh), f"{case} prec {prec}"
+        for tree in TREES:
+            bvh = be.intersect(sc, o, d, precision=prec, accel=tree)
+            assert _same(lin, bvh), f"{case} prec {prec} tree {tree}"
         if case != "degenerate":
             assert (lin[0] >= 0).sum() > 1000
     # and a render through both pipelines on the tree
     from rustraytracer_amd import config as cfg
     rc = cfg.stratified_config(32, 32, 2, 2)
-    a = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LBVH, pipeline=api.PIPELINE_FUSED))
-    b = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LBVH, pipeline=api.PIPELINE_WAVEFRONT))
     c = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LINEAR, pipeline=api.PIPELINE_FUSED))
-    assert a[1]["rays"] == b[1]["rays"] == c[1]["rays"] and a[1]["bounces"] == b[1]["bounces"] == c[1]["bounces"]
+    for tree in TREES:
+        a = be.render_accumulate(sc, rc.render_desc(accel=tree, pipeline=api.PIPELINE_FUSED))
+        b = be.render_accumulate(sc, rc.render_desc(accel=tree, pipeline=api.PIPELINE_WAVEFRONT))
+        assert a[1]["rays"] == b[1]["rays"] == c[1]["rays"] and a[1]["bounces"] == b[1]["bounces"] == c[1]["bounces"]
 
 
 def test_empty_scene(gpu, cfg):
     api, be = gpu
     sc = api.Scene(S.make_scene([], []))
     o, d = _rays(100, seed=1)
-    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH):
+    for accel in (api.ACCEL_LINEAR,) + TREES:
         got = be.intersect(sc, o, d, accel=accel)
         assert np.all(got[0] == -1) and np.all(np.isinf(got[2]))
     rc = cfg.stratified_config(16, 16, 2, 2)
@@ -233,9 +241,10 @@ def test_million_triangle_scene_tree_equals_scan(gpu, cfg, O):
     sc = api.Scene(flat)
     rng = np.random.default_rng(9)
     u, v = rng.random(6000), rng.random(6000)
-    tree = be.trace_primary(sc, u, v, precision=api.PRECISION_F32)  # AUTO -> tree
+    tree = be.trace_primary(sc, u, v, precision=api.PRECISION_F32)  # AUTO -> the surface-area tree
     scan = be.trace_primary(sc, u, v, precision=api.PRECISION_F32, accel=api.ACCEL_LINEAR)
     assert _same(tree, scan)
+    assert _same(be.trace_primary(sc, u, v, precision=api.PRECISION_F32, accel=api.ACCEL_LBVH), scan)
     assert (tree[0] >= 4).sum() > 1000  # a good share of the rays meets the two meshes
     # scattered rays: leave the primary hit points in random directions
     hit = tree[0] >= 0
@@ -246,9 +255,9 @@ def test_million_triangle_scene_tree_equals_scan(gpu, cfg, O):
     d2 = rng.normal(size=o2.shape)
     d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
     for prec in (api.PRECISION_F32, api.PRECISION_F64):
-        a = be.intersect(sc, o2, d2, precision=prec)
         b = be.intersect(sc, o2, d2, precision=prec, accel=api.ACCEL_LINEAR)
-        assert _same(a, b), prec
+        for accel in (api.ACCEL_AUTO,) + TREES:
+            assert _same(be.intersect(sc, o2, d2, precision=prec, accel=accel), b), (prec, accel)
     n = 200
     ref = O.trace_primary(flat, u[:n], v[:n])
     got = be.trace_primary(sc, u[:n], v[:n], precision=api.PRECISION_F64)

@@ -40,10 +40,12 @@ def test_same_paths_as_fused_linear(gpu, cfg, scenes, name):
 def test_same_paths_as_fused_lbvh(gpu, cfg, cornell):
     api, be = gpu
     sc = api.Scene(cornell)
-    same_paths(*both(api, be, sc, cfg.stratified_config(96, 96, 4, 4), api.ACCEL_LBVH))
+    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH):
+        same_paths(*both(api, be, sc, cfg.stratified_config(96, 96, 4, 4), tree))
     # all primitive types and all materials, planes beside the tree
     sc = api.Scene(S.all_prims_scene())
-    same_paths(*both(api, be, sc, cfg.stratified_config(80, 60, 4, 4), api.ACCEL_LBVH))
+    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH):
+        same_paths(*both(api, be, sc, cfg.stratified_config(80, 60, 4, 4), tree))
 
 
 def test_queue_smaller_than_the_render(gpu, cfg, cornell, monkeypatch):

@@ -23,7 +23,7 @@ def test_static_equals_allocating_entry_point_twice(gpu, O):
     assert 40000 < len(o_big) <= _abi.INTERSECT_STATIC_MAX_RAYS
     o_small, d_small = S.secondary_rays(flat, O, 700, seed=22)
     for prec in (api.PRECISION_F32, api.PRECISION_F64):
-        for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH):
+        for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH):
             want_big = be.intersect(sc, o_big, d_big, precision=prec, accel=accel)   # also makes scene (and tree) resident
             want_small = be.intersect(sc, o_small, d_small, precision=prec, accel=accel)
             got_big = be.intersect_static(sc, o_big, d_big, precision=prec, accel=accel)
@@ -50,7 +50,12 @@ def test_static_limits_are_errors(gpu, O):
     be.intersect(sc, o[:8], d[:8], accel=api.ACCEL_LINEAR)
     with pytest.raises(api.RrtError) as e:   # resident, but its tree is not built
         be.intersect_static(sc, o[:8], d[:8], accel=api.ACCEL_LBVH)
-    assert e.value.code == -1 and "LBVH" in str(e.value)
+    assert e.value.code == -1 and "tree is not built" in str(e.value)
+    be.intersect(sc, o[:8], d[:8], accel=api.ACCEL_LBVH)
+    be.intersect_static(sc, o[:8], d[:8], accel=api.ACCEL_LBVH)
+    with pytest.raises(api.RrtError) as e:   # each kind of tree is built by a call that asks for that kind
+        be.intersect_static(sc, o[:8], d[:8], accel=api.ACCEL_SAH)
+    assert e.value.code == -1 and "tree is not built" in str(e.value)
     with pytest.raises(api.RrtError) as e:
         be.intersect_static(sc, o, d, accel=api.ACCEL_LINEAR)
     assert e.value.code == -1 and "at most" in str(e.value)

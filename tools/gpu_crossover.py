@@ -14,7 +14,8 @@ for n in sizes:
     flat = T.mesh_scene(n)
     sc = api.Scene(flat)
     row = []
-    combos = ((api.ACCEL_LINEAR, api.PIPELINE_FUSED), (api.ACCEL_LBVH, api.PIPELINE_FUSED), (api.ACCEL_LBVH, api.PIPELINE_WAVEFRONT))
+    combos = ((api.ACCEL_LINEAR, api.PIPELINE_FUSED), (api.ACCEL_LBVH, api.PIPELINE_FUSED), (api.ACCEL_LBVH, api.PIPELINE_WAVEFRONT),
+              (api.ACCEL_SAH, api.PIPELINE_FUSED), (api.ACCEL_SAH, api.PIPELINE_WAVEFRONT))
     for accel, pipe in combos:
         if large and accel == api.ACCEL_LINEAR:
             row.append(float("nan"))
@@ -22,7 +23,8 @@ for n in sizes:
         for rep in range(2):
             rgb, st = be.render_accumulate(sc, rc.render_desc(accel=accel, pipeline=pipe))
         row.append(st["rays"] / st["kernel_ms"] / 1e3)
-    print("prims %7d  linear/fused %8.0f  tree/fused %8.0f  tree/wavefront %8.0f Mrays/s" % (flat.n_prims, *row), flush=True)
+    print("prims %7d  linear/fused %8.0f  radix tree fused %8.0f wavefront %8.0f  surface-area tree fused %8.0f wavefront %8.0f Mrays/s"
+          % (flat.n_prims, *row), flush=True)
 if large:
     import make_c5_assets
     make_c5_assets.main()
@@ -30,8 +32,10 @@ if large:
     sc = api.Scene(flat)
     rc = config.stratified_config(1920, 1080, 8, 8)
     row = []
-    for pipe in (api.PIPELINE_FUSED, api.PIPELINE_WAVEFRONT):
-        for rep in range(2):
-            rgb, st = be.render_accumulate(sc, rc.render_desc(accel=api.ACCEL_LBVH, pipeline=pipe))
-        row.append(st["rays"] / st["kernel_ms"] / 1e3)
-    print("mesh_1m %7d prims  tree/fused %8.0f  tree/wavefront %8.0f Mrays/s" % (flat.n_prims, *row), flush=True)
+    for accel in (api.ACCEL_LBVH, api.ACCEL_SAH):
+        for pipe in (api.PIPELINE_FUSED, api.PIPELINE_WAVEFRONT):
+            for rep in range(2):
+                rgb, st = be.render_accumulate(sc, rc.render_desc(accel=accel, pipeline=pipe))
+            row.append(st["rays"] / st["kernel_ms"] / 1e3)
+    print("mesh_1m %7d prims  radix tree fused %8.0f wavefront %8.0f  surface-area tree fused %8.0f wavefront %8.0f Mrays/s"
+          % (flat.n_prims, *row), flush=True)
