@@ -71,7 +71,7 @@ typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_
  *   LBVH  Morton-code radix tree built on the GPU (~0.3 s per million primitives including the upload);
  *   SAH   binned surface-area-heuristic tree built by up to 16 host threads (~0.4 s per million primitives),
  *         about a seventh fewer traversal steps per ray.
- * AUTO = LINEAR for scenes of up to 160 primitives (where it is the fastest), SAH otherwise.  A scene keeps every
+ * AUTO = LINEAR for scenes of up to 100 primitives (where it is the fastest), SAH otherwise.  A scene keeps every
  * tree it was asked for (per device) until rrt_scene_destroy. */
 typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2, RRT_ACCEL_SAH = 3 } rrt_accel;
 
@@ -79,7 +79,7 @@ typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBV
  * all of its bounces and refills finished lanes with new camera samples;
  * WAVEFRONT keeps SoA ray and hit queues in HBM and compacts them after every
  * bounce (f32 only, max_depth <= 511).  AUTO: WAVEFRONT when the closest hit
- * goes through the tree of a scene with more than 16000 primitives and the
+ * goes through the tree of a scene with more than 50000 primitives and the
  * precision is f32, FUSED otherwise.  Both trace the same paths for the same seed. */
 typedef enum rrt_pipeline { RRT_PIPELINE_AUTO = 0, RRT_PIPELINE_FUSED = 1, RRT_PIPELINE_WAVEFRONT = 2 } rrt_pipeline;
 

@@ -436,15 +436,17 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
 };
 
-// Scenes with more primitives than this get the LBVH under RRT_ACCEL_AUTO, and tree scenes with more
+// Scenes with more primitives than this get the surface-area tree under RRT_ACCEL_AUTO, and tree scenes with more
 // primitives than kAutoWavefrontThreshold the wavefront pipeline under RRT_PIPELINE_AUTO.  Measured on
 // triangle meshes at 1024x1024 @ 256 spp (tools/gpu_crossover.py), Grays/s:
-//   primitives       50     92    184    382    758   1484   5854  23718  99858  399426
-//   scan, fused    25.9   15.8    8.5    4.2    2.2    1.1    0.3
-//   tree, fused    15.5   13.1   11.8   10.8    9.2    8.1    7.3    5.9    5.0    4.0
-//   tree, wavefront 7.7    7.3    7.2    7.1    7.0    6.8    6.6    6.1    6.0    5.6   (1 M triangles: 5.2 against 2.3 fused)
-const size_t kAutoBvhThreshold = 160;
-const size_t kAutoWavefrontThreshold = 16000;
+//   primitives             26     50     92    184    382    758   1484   5854  23718  99858  399426
+//   scan, fused          42.2   27.1   16.4    8.8    4.3    2.2    1.1    0.3
+//   radix tree, fused    24.4   17.8   14.3   12.8   12.0   10.6    9.4    8.0    6.6    5.5    4.5
+//   radix tree, wavefront 7.9    7.6    7.3    7.2    7.1    7.0    6.8    6.6    6.2    6.0    5.6
+//   area tree, fused     23.6   19.9   17.2   14.4   12.5   11.5   10.5    8.5    7.4    5.9    4.5
+//   area tree, wavefront  7.9    7.8    7.7    7.5    7.3    7.2    7.0    6.8    6.5    6.2    6.2
+const size_t kAutoBvhThreshold = 100;
+const size_t kAutoWavefrontThreshold = 50000;
 // Subtrees of at most this many primitives are folded into one leaf.  A traversal step costs one
 // 64-byte fetch whether it reads a node or a primitive; 2 minimises their sum on triangle meshes.
 const int kBvhLeafMax = 2;

@@ -5,6 +5,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdint>
 #include <thread>
 #include <vector>
@@ -26,7 +27,10 @@ struct SahBox {
 
 class SahBuilder {
 public:
-    static constexpr int BINS = 16;
+#ifndef RRT_SAH_BINS
+#define RRT_SAH_BINS 16
+#endif
+    static constexpr int BINS = RRT_SAH_BINS;
     SahBuilder(const float* lo, const float* hi, int n, int leaf_max) : lo_(lo), hi_(hi), n_(n), leaf_max_(leaf_max) {}
 
     // nodes: at most n - 1 records, node 0 the root; prim_of_slot: n entries.  Needs n >= 2.
@@ -37,9 +41,17 @@ public:
         prim_of_slot.resize((size_t)n_);
         for (int i = 0; i < n_; ++i) prim_of_slot[(size_t)i] = i;
         idx_ = prim_of_slot.data();
+        size_.resize((size_t)n_);
+        for (int i = 0; i < n_; ++i) {
+            SahBox b;
+            b.clear();
+            b.grow(lo_ + 3 * (size_t)i, hi_ + 3 * (size_t)i);
+            size_[(size_t)i] = std::log2(std::max(b.half_area(), 1e-30f));
+        }
         nodes.clear();
         nodes.reserve((size_t)n_);
         nodes.emplace_back();
+        top_threads_ = std::max(1, threads);
         const int grain = std::max(4096, n_ / 64);
         std::vector<Job> jobs;
         if (n_ <= grain) jobs.push_back({0, 0, n_});
@@ -71,11 +83,65 @@ public:
     }
 
 private:
+#ifndef RRT_SAH_WEIGHT
+#define RRT_SAH_WEIGHT(n) ((float)(n))
+#endif
+    static float weight(int n) { return RRT_SAH_WEIGHT(n); }
     const float* lo_;
     const float* hi_;
     int n_, leaf_max_;
     int32_t* idx_ = nullptr;
     struct Job { int id, first, count; };
+    // Cuts are tried along four coordinates of a primitive: the three of its box centre and, as a fourth, the
+    // logarithm of its box area.  A cut along the fourth one takes the few large primitives of a range (the walls
+    // of a room around a mesh) apart from the many small ones; cuts by position cannot, because a large box
+    // keeps its side of the cut as large as the whole range for level after level.
+    static constexpr int AXES = 4;
+    std::vector<float> size_;  // log2 of the half area of every primitive's box
+    float coord(size_t p, int a) const { return a < 3 ? 0.5f * (lo_[3 * p + a] + hi_[3 * p + a]) : size_[p]; }
+    int top_threads_ = 1;
+    struct Extent {
+        float lo[AXES], hi[AXES];
+        void clear() { for (int a = 0; a < AXES; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; } }
+    };
+    struct Bins {
+        SahBox box[AXES][BINS];
+        int n[AXES][BINS];
+        void clear() { for (int a = 0; a < AXES; ++a) for (int b = 0; b < BINS; ++b) { box[a][b].clear(); n[a][b] = 0; } }
+    };
+    void extent(int first, int count, Extent& e) const {
+        for (int i = first; i < first + count; ++i) {
+            const size_t p = (size_t)idx_[i];
+            for (int a = 0; a < AXES; ++a) {
+                const float c = coord(p, a);
+                e.lo[a] = std::min(e.lo[a], c);
+                e.hi[a] = std::max(e.hi[a], c);
+            }
+        }
+    }
+    void fill_bins(int first, int count, const float* clo, const float* scale, Bins& bins) const {
+        for (int i = first; i < first + count; ++i) {
+            const size_t p = (size_t)idx_[i];
+            for (int a = 0; a < AXES; ++a) {
+                int b = (int)((coord(p, a) - clo[a]) * scale[a]);
+                b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
+                bins.box[a][b].grow(lo_ + 3 * p, hi_ + 3 * p);
+                bins.n[a][b] += 1;
+            }
+        }
+    }
+    // fn(chunk, first, count) over `chunks` equal parts of a range, on as many threads
+    template <typename F>
+    static void run_chunks(int first, int count, int chunks, F fn) {
+        if (chunks <= 1) { fn(0, first, count); return; }
+        std::vector<std::thread> pool;
+        for (int c = 0; c < chunks; ++c) {
+            const int f = first + (int)((long long)count * c / chunks), l = first + (int)((long long)count * (c + 1) / chunks);
+            if (c + 1 < chunks) pool.emplace_back(fn, c, f, l - f);
+            else fn(c, f, l - f);
+        }
+        for (std::thread& t : pool) t.join();
+    }
 
     SahBox bounds_of(int first, int count) const {
         SahBox b;
@@ -86,20 +152,27 @@ private:
 
     // Small ranges: every cut of the order along every axis is tried (bins are too coarse to keep the
     // two triangles of a mesh cell together).
-    static constexpr int SWEEP_MAX = 32;
+#ifndef RRT_SAH_SWEEP
+#define RRT_SAH_SWEEP 32
+#endif
+    static constexpr int SWEEP_MAX = RRT_SAH_SWEEP;
     int partition_sweep(int first, int count) {
-        std::pair<float, int32_t> key[SWEEP_MAX];
-        int32_t best_order[SWEEP_MAX];
-        float right_area[SWEEP_MAX];
+        thread_local std::vector<std::pair<float, int32_t>> key_v;
+        thread_local std::vector<float> area_v;
+        if ((int)key_v.size() < count) { key_v.resize((size_t)count); area_v.resize((size_t)count); }
+        std::pair<float, int32_t>* key = key_v.data();
+        float* right_area = area_v.data();
         float best_cost = 3.0e38f;
-        int best_nl = count / 2;
-        bool found = false;
-        for (int a = 0; a < 3; ++a) {
+        int best_nl = count / 2, best_axis = -1;
+        auto sort_along = [&](int a) {
             for (int i = 0; i < count; ++i) {
                 const int32_t p = idx_[first + i];
-                key[i] = {0.5f * (lo_[3 * (size_t)p + a] + hi_[3 * (size_t)p + a]), p};
+                key[i] = {coord((size_t)p, a), p};
             }
             std::sort(key, key + count);
+        };
+        for (int a = 0; a < AXES; ++a) {
+            sort_along(a);
             SahBox acc;
             acc.clear();
             for (int i = count - 1; i > 0; --i) {
@@ -111,51 +184,48 @@ private:
                 acc.grow(lo_ + 3 * (size_t)key[i].second, hi_ + 3 * (size_t)key[i].second);
                 const int nl = i + 1, nr = count - nl;
                 // leaves hold up to leaf_max_ primitives: a part of that size costs one box, whatever it holds
-                const float cost = acc.half_area() * (float)(nl <= leaf_max_ ? 1 : nl) + right_area[i + 1] * (float)(nr <= leaf_max_ ? 1 : nr);
+                const float cost = acc.half_area() * (nl <= leaf_max_ ? 1.f : weight(nl)) + right_area[i + 1] * (nr <= leaf_max_ ? 1.f : weight(nr));
                 if (cost < best_cost) {
                     best_cost = cost;
                     best_nl = nl;
-                    found = true;
-                    for (int k = 0; k < count; ++k) best_order[k] = key[k].second;
+                    best_axis = a;
                 }
             }
         }
-        if (found)
-            for (int k = 0; k < count; ++k) idx_[first + k] = best_order[k];
+        if (best_axis >= 0) {
+            if (best_axis != AXES - 1) sort_along(best_axis);
+            for (int k = 0; k < count; ++k) idx_[first + k] = key[k].second;
+        }
         return best_nl;
     }
 
     // Where to cut [first, first + count): returns the size of the left part (1 .. count - 1).
     int partition(int first, int count) {
         if (count <= SWEEP_MAX) return partition_sweep(first, count);
-        float clo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, chi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-        for (int i = first; i < first + count; ++i) {
-            const size_t p = (size_t)idx_[i];
-            for (int a = 0; a < 3; ++a) {
-                const float c = 0.5f * (lo_[3 * p + a] + hi_[3 * p + a]);
-                clo[a] = std::min(clo[a], c);
-                chi[a] = std::max(chi[a], c);
-            }
-        }
+        Extent ext;
+        ext.clear();
+        const int chunks = count >= 65536 ? top_threads_ : 1;  // only the ranges at the top of the tree are that large
+        std::vector<Extent> ext_part((size_t)chunks);
+        run_chunks(first, count, chunks, [&](int c, int f, int n) { ext_part[(size_t)c].clear(); extent(f, n, ext_part[(size_t)c]); });
+        for (const Extent& e : ext_part)
+            for (int a = 0; a < AXES; ++a) { ext.lo[a] = std::min(ext.lo[a], e.lo[a]); ext.hi[a] = std::max(ext.hi[a], e.hi[a]); }
+        const float* clo = ext.lo;
+        const float* chi = ext.hi;
         float best_cost = 3.0e38f;
         int best_axis = -1, best_bin = 0;
         float best_scale = 0.f;
-        float scale[3];
-        for (int a = 0; a < 3; ++a) scale[a] = chi[a] > clo[a] ? (float)BINS * (1.f - 1e-6f) / (chi[a] - clo[a]) : 0.f;
-        SahBox bin_box[3][BINS];
-        int bin_n[3][BINS];
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < BINS; ++b) { bin_box[a][b].clear(); bin_n[a][b] = 0; }
-        for (int i = first; i < first + count; ++i) {
-            const size_t p = (size_t)idx_[i];
-            for (int a = 0; a < 3; ++a) {
-                int b = (int)((0.5f * (lo_[3 * p + a] + hi_[3 * p + a]) - clo[a]) * scale[a]);
-                b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
-                bin_box[a][b].grow(lo_ + 3 * p, hi_ + 3 * p);
-                bin_n[a][b] += 1;
-            }
-        }
-        for (int a = 0; a < 3; ++a) {
+        float scale[AXES];
+        for (int a = 0; a < AXES; ++a) scale[a] = chi[a] > clo[a] ? (float)BINS * (1.f - 1e-6f) / (chi[a] - clo[a]) : 0.f;
+        std::vector<Bins> bins_part((size_t)chunks);
+        run_chunks(first, count, chunks, [&](int c, int f, int n) { bins_part[(size_t)c].clear(); fill_bins(f, n, clo, scale, bins_part[(size_t)c]); });
+        Bins& bins = bins_part[0];
+        for (int c = 1; c < chunks; ++c)
+            for (int a = 0; a < AXES; ++a)
+                for (int k = 0; k < BINS; ++k)
+                    if (bins_part[(size_t)c].n[a][k]) { bins.box[a][k].grow(bins_part[(size_t)c].box[a][k]); bins.n[a][k] += bins_part[(size_t)c].n[a][k]; }
+        auto& bin_box = bins.box;
+        auto& bin_n = bins.n;
+        for (int a = 0; a < AXES; ++a) {
             if (!(scale[a] > 0.f)) continue;
             float right_area[BINS];
             SahBox acc;
@@ -171,14 +241,14 @@ private:
                 nl += bin_n[a][b];
                 const int nr = count - nl;
                 if (nl == 0 || nr == 0) continue;
-                const float cost = acc.half_area() * (float)nl + right_area[b + 1] * (float)nr;
+                const float cost = acc.half_area() * weight(nl) + right_area[b + 1] * weight(nr);
                 if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; best_scale = scale[a]; }
             }
         }
         if (best_axis < 0) return count / 2;  // all centres coincide: any cut is as good
         const int a = best_axis;
         int32_t* mid = std::partition(idx_ + first, idx_ + first + count, [&](int32_t p) {
-            int b = (int)((0.5f * (lo_[3 * (size_t)p + a] + hi_[3 * (size_t)p + a]) - clo[a]) * best_scale);
+            int b = (int)((coord((size_t)p, a) - clo[a]) * best_scale);
             b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
             return b <= best_bin;
         });

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
 // one-ray-per-lane leaves most lanes idle most of the time.  Here a wave is persistent: it walks its
 // blocks of 64 rays and hands the next rays to lanes as they finish, whenever at least
 // WF_REFILL_MIN lanes are idle.
-constexpr int WF_REFILL_MIN = 16;  // (64 Mi-path queues: 8 -> 5.80, 12 -> 5.95, 16 -> 6.00, 20 -> 5.99 Grays/s on the million-triangle scene)
+constexpr int WF_REFILL_MIN = 20;  // (64 Mi-path queues, million-triangle scene; radix tree: 8 -> 5.80, 12 -> 5.95, 16 -> 6.00, 20 -> 5.99 Grays/s; surface-area tree: 16 -> 6.36, 20 -> 6.40, 24 -> 6.30)
 
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
 wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min) {

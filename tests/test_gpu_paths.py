@@ -171,14 +171,15 @@ def _two_mesh_scene(n_tri_each):
 
 
 def test_mesh_scene_through_tree_and_wavefront_same_paths(gpu, O, cfg):
-    """20 000 triangles: AUTO takes the LBVH and, in f32, the wavefront pipeline (persistent tree-walk kernel, ray
-    queues, compaction); the oracle scans every triangle for every ray.  Same paths, so the same pixels."""
+    """20 000 triangles through the tree AUTO builds, with the fused kernel (f64) and with the wavefront pipeline
+    (f32: persistent tree-walk kernel, ray queues, compaction; what AUTO takes for larger scenes); the oracle scans
+    every triangle for every ray.  Same paths, so the same pixels."""
     api, be = gpu
     flat = _two_mesh_scene(10000)
     assert flat.n_prims > 15000
     rc = cfg.stratified_config(64, 64, 2, 2, max_depth=8, seed=71)
     bad = _compare(api, be, O, cfg, flat, rc, max_bad=4)                      # f64: fused kernel + tree
-    frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_AUTO, "two meshes")  # f32: wavefront + tree
+    frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_WAVEFRONT, "two meshes")  # f32: wavefront + tree
     print("f64 pixels off:", bad)
     assert frac <= 0.01 and rel_rays <= 3e-4
 
