@@ -440,11 +440,11 @@ struct DevBuf {
 // primitives than kAutoWavefrontThreshold the wavefront pipeline under RRT_PIPELINE_AUTO.  Measured on
 // triangle meshes at 1024x1024 @ 256 spp (tools/gpu_crossover.py), Grays/s:
 //   primitives             26     50     92    184    382    758   1484   5854  23718  99858  399426
-//   scan, fused          42.2   27.1   16.4    8.8    4.3    2.2    1.1    0.3
-//   radix tree, fused    24.4   17.8   14.3   12.8   12.0   10.6    9.4    8.0    6.6    5.5    4.5
-//   radix tree, wavefront 7.9    7.6    7.3    7.2    7.1    7.0    6.8    6.6    6.2    6.0    5.6
-//   area tree, fused     23.6   19.9   17.2   14.4   12.5   11.5   10.5    8.5    7.4    5.9    4.5
-//   area tree, wavefront  7.9    7.8    7.7    7.5    7.3    7.2    7.0    6.8    6.5    6.2    6.2
+//   scan, fused          41.8   26.9   16.2    8.6    4.3    2.2    1.2    0.3
+//   radix tree, fused    24.5   17.3   14.4   12.8   12.0   10.6    9.4    8.0    6.6    5.5    4.5
+//   radix tree, wavefront 8.0    7.7    7.3    7.2    7.1    6.9    6.8    6.6    6.2    6.0    5.9
+//   area tree, fused     23.5   19.7   17.0   14.7   12.6   11.3   10.6    8.7    7.2    5.9    4.7
+//   area tree, wavefront  8.0    7.8    7.7    7.5    7.3    7.2    7.1    6.8    6.5    6.2    6.2
 const size_t kAutoBvhThreshold = 100;
 const size_t kAutoWavefrontThreshold = 50000;
 // Subtrees of at most this many primitives are folded into one leaf.  A traversal step costs one

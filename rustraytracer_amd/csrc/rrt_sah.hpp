@@ -96,7 +96,10 @@ private:
     // logarithm of its box area.  A cut along the fourth one takes the few large primitives of a range (the walls
     // of a room around a mesh) apart from the many small ones; cuts by position cannot, because a large box
     // keeps its side of the cut as large as the whole range for level after level.
-    static constexpr int AXES = 4;
+#ifndef RRT_SAH_AXES
+#define RRT_SAH_AXES 4
+#endif
+    static constexpr int AXES = RRT_SAH_AXES;
     std::vector<float> size_;  // log2 of the half area of every primitive's box
     float coord(size_t p, int a) const { return a < 3 ? 0.5f * (lo_[3 * p + a] + hi_[3 * p + a]) : size_[p]; }
     int top_threads_ = 1;
