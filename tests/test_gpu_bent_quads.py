@@ -27,7 +27,7 @@ def test_bent_quads_against_the_oracle(gpu, O, name):
     margin = _margin(flat, quads, o, d)
     hit = ref[0] >= 0
     assert hit.sum() > 0.3 * len(o) and (~hit).sum() > 50
-    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH):
+    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH):
         oid, pid, t = be.intersect(sc, o, d, precision=api.PRECISION_F64, accel=accel)
         assert np.array_equal(oid, ref[0]) and np.array_equal(pid, ref[1]), (name, accel)
         assert np.all(np.abs(t[hit] - ref[2][hit]) <= 1e-11 * np.abs(ref[2][hit]))
@@ -54,8 +54,9 @@ def test_scan_and_tree_agree_bit_for_bit_on_bent_quads(gpu):
         sc = api.Scene(flat)
         for prec in (api.PRECISION_F64, api.PRECISION_F32):
             a = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LINEAR)
-            b = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LBVH)
-            assert all(np.array_equal(x, y) for x, y in zip(a, b)), (name, prec)
+            for tree in (api.ACCEL_LBVH, api.ACCEL_SAH):
+                b = be.intersect(sc, o, d, precision=prec, accel=tree)
+                assert all(np.array_equal(x, y) for x, y in zip(a, b)), (name, prec, tree)
 
 
 def test_bent_quad_render_follows_the_oracle(gpu, O, cfg):

@@ -50,7 +50,7 @@ def test_every_material_and_the_tree(gpu, O, cfg, cornell):
     rc = cfg.stratified_config(48, 36, 4, 4, min_depth=1, max_depth=8, seed=44)
     _compare(api, be, O, S.all_prims_scene(), rc, api.PRECISION_F64, max_bad=4)
     _compare(api, be, O, S.all_prims_scene(), rc, api.PRECISION_F64, max_bad=4, accel=api.ACCEL_LBVH)
-    _compare(api, be, O, cornell, cfg.stratified_config(48, 48, 4, 4, seed=45), api.PRECISION_F64, max_bad=3, accel=api.ACCEL_LBVH)
+    _compare(api, be, O, cornell, cfg.stratified_config(48, 48, 4, 4, seed=45), api.PRECISION_F64, max_bad=3, accel=api.ACCEL_SAH)
 
 
 def test_converges_to_the_reference_estimator(gpu, cfg, cornell):

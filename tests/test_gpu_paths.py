@@ -53,11 +53,12 @@ def test_every_primitive_and_material_same_paths(gpu, O, cfg):
 
 
 def test_same_paths_through_the_tree(gpu, O, cfg, cornell):
-    """Closest hit through the LBVH instead of the scan: the same primitive and t for every ray, so the same image."""
+    """Closest hit through either tree instead of the scan: the same primitive and t for every ray, so the same image."""
     api, be = gpu
-    _compare(api, be, O, cfg, cornell, cfg.stratified_config(64, 64, 4, 4, seed=31), max_bad=3, accel=api.ACCEL_LBVH)
-    _compare(api, be, O, cfg, S.all_prims_scene(), cfg.stratified_config(64, 48, 4, 4, max_depth=8, seed=32), max_bad=4,
-             accel=api.ACCEL_LBVH)
+    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH):
+        _compare(api, be, O, cfg, cornell, cfg.stratified_config(64, 64, 4, 4, seed=31), max_bad=3, accel=tree)
+        _compare(api, be, O, cfg, S.all_prims_scene(), cfg.stratified_config(64, 48, 4, 4, max_depth=8, seed=32), max_bad=4,
+                 accel=tree)
 
 
 def test_sample_range_shards_same_paths(gpu, O, cfg, cornell):
@@ -213,7 +214,7 @@ def test_ties_and_degenerate_inputs_same_paths(gpu, O, cfg):
     api, be = gpu
     flat = _nasty_scene()
     rc = cfg.stratified_config(96, 72, 4, 4, min_depth=1, max_depth=10, seed=81)
-    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH):
+    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH):
         bad = _compare(api, be, O, cfg, flat, rc, max_bad=6, accel=accel)
         print("accel", accel, "f64 pixels off:", bad)
     frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_FUSED, "nasty fused")
@@ -241,7 +242,7 @@ def test_million_triangle_scene_same_paths(gpu, O, cfg):
     with O.accelerated(flat):
         ref64, rst64 = O.render_accumulate(flat, rc.render_desc(), device_numbers=True)
         ref32, rst32 = O.render_accumulate(flat, rc.render_desc(), device_numbers="f32")
-    dev, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64, accel=api.ACCEL_LBVH))
+    dev, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64, accel=api.ACCEL_SAH))
     err = np.abs(dev.astype(np.float64) - ref64)
     bad = int(np.any(err > 4e-7 * np.abs(ref64) + 1e-9, axis=-1).sum())
     print("mesh_1m f64: pixels off %d of %d, rays %d / %d" % (bad, rc.width * rc.height, st["rays"], rst64["rays_live"]))
