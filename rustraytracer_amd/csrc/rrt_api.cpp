@@ -570,7 +570,8 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
             std::vector<rrt::BvhNode> binary;
             const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
             rrt::SahBuilder(lo.data(), hi.data(), n, leaf_max).build(binary, map, threads);
-            HIP_TRY(rrt::bvh_widen_host_tree(binary.data(), (int)binary.size(), (rrt::WideNode*)nodes, be->stream));
+            static const bool marks = [] { const char* e = getenv("RRT_DEBUG_WIDEN_MARKS"); return e ? atoi(e) != 0 : true; }();  // experiments
+            HIP_TRY(rrt::bvh_widen_host_tree(binary.data(), (int)binary.size(), marks, (rrt::WideNode*)nodes, be->stream));
         } else {
             DevBuf dlo, dhi;
             HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));

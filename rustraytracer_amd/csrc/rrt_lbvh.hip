@@ -180,9 +180,10 @@ __global__ void __launch_bounds__(256) widen_kernel(const BvhNode* __restrict__ 
 // widen_kernel does, spends slots on small children of lopsided subtrees.  Which binary nodes become wide nodes is
 // then known only top-down: state[i] = 1 marks a node whose turn it is, 2 a finished one; every launch handles the
 // marked nodes and marks their internal children, the host repeats it until a launch marks nothing.
+// use_marks: the tree's builder has chosen the children itself (BvhNode::pad0, SAH_OPEN_* bits; rrt_sah.hpp).
 __global__ void __launch_bounds__(256)
 widen_greedy_kernel(const BvhNode* __restrict__ nodes, int n, WideNode* __restrict__ wide, int* __restrict__ state,
-                    int* __restrict__ marked) {
+                    int* __restrict__ marked, int use_marks) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     if (__hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) return;
@@ -199,7 +200,23 @@ widen_greedy_kernel(const BvhNode* __restrict__ nodes, int n, WideNode* __restri
         put(1, N.lo1, N.hi1, N.c1);
         k = 2;
     }
-    while (k < 4) {
+    if (use_marks) {
+        const int32_t shape = nodes[i].pad0;
+        auto open = [&](int at) {  // the child in slot `at` gives way to its two children; returns the slot of the second one
+            const BvhNode C = nodes[child[at]];
+            put(at, C.lo0, C.hi0, C.c0);
+            put(k, C.lo1, C.hi1, C.c1);
+            return k++;
+        };
+        int left1 = -1, right1 = -1;
+        if ((shape & SAH_OPEN_LEFT) && child[0] >= 0) left1 = open(0);
+        if ((shape & SAH_OPEN_RIGHT) && child[1] >= 0 && k < 4) right1 = open(1);
+        if ((shape & SAH_OPEN_LEFT_0) && left1 >= 0 && child[0] >= 0 && k < 4) open(0);
+        if ((shape & SAH_OPEN_LEFT_1) && left1 >= 0 && child[left1] >= 0 && k < 4) open(left1);
+        if ((shape & SAH_OPEN_RIGHT_0) && right1 >= 0 && child[1] >= 0 && k < 4) open(1);
+        if ((shape & SAH_OPEN_RIGHT_1) && right1 >= 0 && child[right1] >= 0 && k < 4) open(right1);
+    }
+    while (!use_marks && k < 4) {
         int best = -1;
         float best_area = -1.f;
         for (int c = 0; c < k; ++c) {
@@ -307,7 +324,7 @@ refit_kernel(const float* __restrict__ lo, const float* __restrict__ hi, const i
 }
 
 // Runs widen_greedy_kernel level by level from the root until no node is marked any more.  state: n ints.
-static hipError_t widen_greedy(const BvhNode* d_nodes, int n, WideNode* wide_tmp, int* state, int max_rounds, hipStream_t stream) {
+static hipError_t widen_greedy(const BvhNode* d_nodes, int n, WideNode* wide_tmp, int* state, int max_rounds, bool use_marks, hipStream_t stream) {
     int* marked = nullptr;
     hipError_t e = hipMalloc(&marked, sizeof(int));
     if (e != hipSuccess) return e;
@@ -319,7 +336,7 @@ static hipError_t widen_greedy(const BvhNode* d_nodes, int n, WideNode* wide_tmp
         int again = 0;
         e = hipMemsetAsync(marked, 0, sizeof(int), stream);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(widen_greedy_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp, state, marked);
+        hipLaunchKernelGGL(widen_greedy_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp, state, marked, use_marks ? 1 : 0);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&again, marked, sizeof(int), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -389,7 +406,7 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
     static const bool greedy = [] { const char* e = getenv("RRT_DEBUG_WIDEN_GREEDY"); return e ? atoi(e) != 0 : true; }();  // experiments
     if (greedy) {
         int* state = range_first;  // free after the collapse
-        LBVH_TRY(widen_greedy(d_nodes, n, wide_tmp, state, 4 * 96, stream));  // no radix tree over 63 + 32 bits is deeper
+        LBVH_TRY(widen_greedy(d_nodes, n, wide_tmp, state, 4 * 96, false, stream));  // no radix tree over 63 + 32 bits is deeper
         hipLaunchKernelGGL(finished_flag_kernel, grid, block, 0, stream, state, n, flag);
         LBVH_TRY(hipGetLastError());
     } else {
@@ -419,7 +436,7 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
 }
 
 // The wide nodes of a binary tree built on the host (rrt_sah.hpp): m binary nodes, node 0 the root.
-hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, WideNode* d_wide, hipStream_t stream) {
+hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, bool use_marks, WideNode* d_wide, hipStream_t stream) {
     if (m < 1) return hipErrorInvalidValue;
     const int n = m + 1;  // the kernels take the primitive count of a full binary tree
     hipError_t e;
@@ -439,7 +456,7 @@ hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, WideNode* d_wide, 
     LBVH_TRY(hipMalloc(&new_index, sizeof(int) * n));
     LBVH_TRY(hipMemcpyAsync(d_nodes, h_nodes, sizeof(BvhNode) * (size_t)m, hipMemcpyHostToDevice, stream));
     dim3 block(256), grid((n + 255) / 256);
-    LBVH_TRY(widen_greedy(d_nodes, n, wide_tmp, state, m, stream));
+    LBVH_TRY(widen_greedy(d_nodes, n, wide_tmp, state, m, use_marks, stream));
     hipLaunchKernelGGL(finished_flag_kernel, grid, block, 0, stream, state, n, flag);
     LBVH_TRY(hipGetLastError());
     size_t scan_bytes = 0;

@@ -13,8 +13,9 @@ namespace rrt {
 hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float scene_lo[3], const float scene_hi[3],
                       int leaf_max, WideNode* d_wide, int* d_prim_of_slot, hipStream_t stream);
 
-// d_wide (m entries) = the wide nodes of a binary tree of m nodes built on the host (rrt_sah.hpp).  Synchronises the stream.
-hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, WideNode* d_wide, hipStream_t stream);
+// d_wide (m entries) = the wide nodes of a binary tree of m nodes built on the host (rrt_sah.hpp).  use_marks: every wide
+// node absorbs the descendants BvhNode::pad0 names (SAH_OPEN_*), else the largest children first.  Synchronises the stream.
+hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, bool use_marks, WideNode* d_wide, hipStream_t stream);
 
 // out[slot] = leaf record of primitive prim_of_slot[slot] (scan-order indices), n entries.
 hipError_t lbvh_pack_leaves(const PrimRec<float>* prims, const int* prim_of_slot, int n, LeafRec<float>* out, hipStream_t s);

@@ -76,6 +76,12 @@ struct MatRec {
 constexpr int BVH_SLOT_BITS = 28;
 constexpr int BVH_SLOT_MASK = (1 << BVH_SLOT_BITS) - 1;
 constexpr int BVH_MAX_PRIMS = BVH_SLOT_MASK;  // so that ~child never equals INT_MIN
+// BvhNode::pad0 of a tree built on the host: which descendants the 4-wide node rooted here absorbs (at most two).
+enum : int32_t {
+    SAH_OPEN_LEFT = 1, SAH_OPEN_RIGHT = 2,       // the node's own children
+    SAH_OPEN_LEFT_0 = 4, SAH_OPEN_LEFT_1 = 8,     // children of the left child (only with SAH_OPEN_LEFT)
+    SAH_OPEN_RIGHT_0 = 16, SAH_OPEN_RIGHT_1 = 32  // children of the right child (only with SAH_OPEN_RIGHT)
+};
 struct alignas(64) BvhNode {
     float lo0[3];
     int32_t c0;

@@ -101,6 +101,24 @@ static void check_tree(const char* name, const Input& in, int leaf_max, const st
         r.count = r0.count + r1.count;
         for (int a = 0; a < 3; ++a) { r.lo[a] = std::fmin(r0.lo[a], r1.lo[a]); r.hi[a] = std::fmax(r0.hi[a], r1.hi[a]); }
     }
+    // the choice of absorbed descendants (BvhNode::pad0): at most two, each an internal node hanging where the bits say
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        const BvhNode& N = nodes[i];
+        const int32_t s = N.pad0;
+        int opened = 0;
+        CHECK((s & ~63) == 0, "%s: node %zu shape %d", name, i, s);
+        if (s & rrt::SAH_OPEN_LEFT) { ++opened; CHECK(N.c0 >= 0, "%s: node %zu opens a leaf", name, i); }
+        if (s & rrt::SAH_OPEN_RIGHT) { ++opened; CHECK(N.c1 >= 0, "%s: node %zu opens a leaf", name, i); }
+        for (int w = 0; w < 2; ++w)
+            for (int x = 0; x < 2; ++x)
+                if (s & (rrt::SAH_OPEN_LEFT_0 << (2 * w + x))) {
+                    ++opened;
+                    const int32_t c = w ? N.c1 : N.c0;
+                    CHECK((s & (rrt::SAH_OPEN_LEFT << w)) && c >= 0, "%s: node %zu opens a grandchild of a closed child", name, i);
+                    if (c >= 0) CHECK((x ? nodes[(size_t)c].c1 : nodes[(size_t)c].c0) >= 0, "%s: node %zu opens a leaf grandchild", name, i);
+                }
+        CHECK(opened <= 2, "%s: node %zu absorbs %d nodes", name, i, opened);
+    }
     CHECK(ret[0].first == 0 && ret[0].count == n, "%s: the root covers [%d, +%d)", name, ret[0].first, ret[0].count);
     for (int s = 0; s < n; ++s) CHECK(seen_slot[(size_t)s] == 1, "%s: slot %d in %d leaves", name, s, seen_slot[(size_t)s]);
     for (size_t i = 0; i < nodes.size(); ++i) CHECK(seen_node[i] == 1, "%s: node %zu reached %d times", name, i, seen_node[i]);
