@@ -150,6 +150,7 @@ private:
 #endif
     static constexpr int AXES = RRT_SAH_AXES;
     std::vector<float> size_;  // log2 of the half area of every primitive's box
+    std::vector<int32_t> temp_;  // scratch of the top-of-tree partition
     float coord(size_t p, int a) const { return a < 3 ? 0.5f * (lo_[3 * p + a] + hi_[3 * p + a]) : size_[p]; }
     int top_threads_ = 1;
     struct Extent {
@@ -208,7 +209,7 @@ private:
 #define RRT_SAH_SWEEP 32
 #endif
     static constexpr int SWEEP_MAX = RRT_SAH_SWEEP;
-    int partition_sweep(int first, int count) {
+    int partition_sweep(int first, int count, SahBox& bl, SahBox& br) {
         thread_local std::vector<std::pair<float, int32_t>> key_v;
         thread_local std::vector<float> area_v;
         if ((int)key_v.size() < count) { key_v.resize((size_t)count); area_v.resize((size_t)count); }
@@ -248,12 +249,14 @@ private:
             if (best_axis != AXES - 1) sort_along(best_axis);
             for (int k = 0; k < count; ++k) idx_[first + k] = key[k].second;
         }
+        bl = bounds_of(first, best_nl);
+        br = bounds_of(first + best_nl, count - best_nl);
         return best_nl;
     }
 
-    // Where to cut [first, first + count): returns the size of the left part (1 .. count - 1).
-    int partition(int first, int count) {
-        if (count <= SWEEP_MAX) return partition_sweep(first, count);
+    // Where to cut [first, first + count): returns the size of the left part (1 .. count - 1) and the boxes of the parts.
+    int partition(int first, int count, SahBox& bl, SahBox& br) {
+        if (count <= SWEEP_MAX) return partition_sweep(first, count, bl, br);
         Extent ext;
         ext.clear();
         const int chunks = count >= 65536 ? top_threads_ : 1;  // only the ranges at the top of the tree are that large
@@ -297,15 +300,50 @@ private:
                 if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; best_scale = scale[a]; }
             }
         }
-        if (best_axis < 0) return count / 2;  // all centres coincide: any cut is as good
+        auto halves = [&]() {  // all centres and sizes coincide: any cut is as good
+            bl = bounds_of(first, count / 2);
+            br = bounds_of(first + count / 2, count - count / 2);
+            return count / 2;
+        };
+        if (best_axis < 0) return halves();
         const int a = best_axis;
-        int32_t* mid = std::partition(idx_ + first, idx_ + first + count, [&](int32_t p) {
+        auto goes_left = [&](int32_t p) {
             int b = (int)((coord((size_t)p, a) - clo[a]) * best_scale);
             b = b < 0 ? 0 : (b >= BINS ? BINS - 1 : b);
             return b <= best_bin;
-        });
-        const int nl = (int)(mid - (idx_ + first));
-        return (nl <= 0 || nl >= count) ? count / 2 : nl;
+        };
+        int nl;
+        if (chunks <= 1) {
+            nl = (int)(std::partition(idx_ + first, idx_ + first + count, goes_left) - (idx_ + first));
+        } else {
+            // a large range in PARTS pieces (a fixed number: the order of the result must not depend on the thread
+            // count), every piece partitioned in place, then the left parts and the right parts gathered through temp_
+            constexpr int PARTS = 16;
+            int begin[PARTS + 1], left[PARTS];
+            for (int c = 0; c <= PARTS; ++c) begin[c] = first + (int)((long long)count * c / PARTS);
+            run_chunks(0, PARTS, std::min(PARTS, top_threads_), [&](int, int c0, int nc) {
+                for (int c = c0; c < c0 + nc; ++c) left[c] = (int)(std::partition(idx_ + begin[c], idx_ + begin[c + 1], goes_left) - (idx_ + begin[c]));
+            });
+            int left_at[PARTS], right_at[PARTS];
+            nl = 0;
+            for (int c = 0; c < PARTS; ++c) { left_at[c] = nl; nl += left[c]; }
+            int nr = 0;
+            for (int c = 0; c < PARTS; ++c) { right_at[c] = nl + nr; nr += begin[c + 1] - begin[c] - left[c]; }
+            if ((int)temp_.size() < count) temp_.resize((size_t)count);
+            run_chunks(0, PARTS, std::min(PARTS, top_threads_), [&](int, int c0, int nc) {
+                for (int c = c0; c < c0 + nc; ++c) {
+                    std::copy(idx_ + begin[c], idx_ + begin[c] + left[c], temp_.data() + left_at[c]);
+                    std::copy(idx_ + begin[c] + left[c], idx_ + begin[c + 1], temp_.data() + right_at[c]);
+                }
+            });
+            run_chunks(0, count, top_threads_, [&](int, int f, int n) { std::copy(temp_.data() + f, temp_.data() + f + n, idx_ + first + f); });
+        }
+        if (nl <= 0 || nl >= count) return halves();
+        bl.clear();
+        br.clear();
+        for (int b = 0; b < BINS; ++b)
+            if (bin_n[a][b]) (b <= best_bin ? bl : br).grow(bin_box[a][b]);  // the bins already hold the boxes of both parts
+        return nl;
     }
 
     // Builds the subtree of out[root] over [first0, first0 + count0).  With `jobs`, ranges of at most `grain`
@@ -324,8 +362,8 @@ private:
         while (!todo.empty()) {
             const Job j = todo.back();
             todo.pop_back();
-            const int nl = partition(j.first, j.count);
-            const SahBox bl = bounds_of(j.first, nl), br = bounds_of(j.first + nl, j.count - nl);
+            SahBox bl, br;
+            const int nl = partition(j.first, j.count, bl, br);
             const int32_t c0 = link(j.first, nl), c1 = link(j.first + nl, j.count - nl);
             BvhNode& N = out[(size_t)j.id];
             for (int a = 0; a < 3; ++a) { N.lo0[a] = bl.lo[a]; N.hi0[a] = bl.hi[a]; N.lo1[a] = br.lo[a]; N.hi1[a] = br.hi[a]; }
