@@ -69,7 +69,7 @@ typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_
  * LBVH and SAH are two builders of one tree format (4-wide nodes, 8-bit child boxes; unbounded planes and quads
  * that are not planar are scanned beside the tree), both returning the primitive and t the scan returns:
  *   LBVH  Morton-code radix tree built on the GPU (~0.3 s per million primitives including the upload);
- *   SAH   binned surface-area-heuristic tree built by up to 16 host threads (~0.4 s per million primitives),
+ *   SAH   binned surface-area-heuristic tree built by up to 16 host threads (~0.5 s per million primitives),
  *         about a seventh fewer traversal steps per ray.
  * AUTO = LINEAR for scenes of up to 100 primitives (where it is the fastest), SAH otherwise.  A scene keeps every
  * tree it was asked for (per device) until rrt_scene_destroy. */
