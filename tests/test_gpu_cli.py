@@ -159,3 +159,26 @@ def test_cli_next_event_flag(gpu, cfg, tmp_path):
     # (the two estimators have the same LINEAR mean, tests/test_gpu_nee.py; after tone mapping and gamma the less noisy
     #  image is the brighter one, so the 8-bit files are not compared with each other)
     assert got.mean() > outs["plain"][0].mean()
+
+
+def test_cli_accel_names(tmp_path):
+    """`rrt --accel linear|lbvh|sah`: the same paths through the scan and through either tree, so the same ray counts
+    and (to float summation order) the same image; an unknown name is a usage error."""
+    from PIL import Image
+    scene = os.path.join(ROOT, "configs", "cornell_box", "scene.toml")
+    rc_path = tmp_path / "r.toml"
+    rc_path.write_text(RENDER.format(sampler="Stratified", strata="x_strata = 8\ny_strata = 8", wb=""))
+    outs = {}
+    for name in ("linear", "lbvh", "sah"):
+        out, stats = tmp_path / (name + ".png"), tmp_path / (name + ".json")
+        r = subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(out), "--stats-json", str(stats), "--accel", name],
+                           capture_output=True, text=True, timeout=120, cwd=ROOT)
+        assert r.returncode == 0, r.stderr
+        outs[name] = (np.asarray(Image.open(out).convert("RGB")).astype(int), json.load(open(stats)))
+    for name in ("lbvh", "sah"):
+        assert outs[name][1]["rays"] == outs["linear"][1]["rays"] and outs[name][1]["node_tests"] > 0
+        assert np.abs(outs[name][0] - outs["linear"][0]).max() <= 1
+    assert outs["linear"][1]["node_tests"] == 0
+    r = subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(tmp_path / "x.png"), "--accel", "octree"],
+                       capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 2
