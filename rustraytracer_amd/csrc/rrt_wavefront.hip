@@ -102,7 +102,10 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
 // WF_REFILL_MIN lanes are idle.
 constexpr int WF_REFILL_MIN = 20;  // (64 Mi-path queues, million-triangle scene; radix tree: 8 -> 5.80, 12 -> 5.95, 16 -> 6.00, 20 -> 5.99 Grays/s; surface-area tree: 16 -> 6.36, 20 -> 6.40, 24 -> 6.30)
 
-__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
+#ifndef RRT_EXP_TREE_WAVES
+#define RRT_EXP_TREE_WAVES 8  // experiment: waves per SIMD the tree kernel is compiled for
+#endif
+__global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(RRT_EXP_TREE_WAVES)))
 wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min) {
     typedef float R;
     __shared__ TreeStackLds s_stack;

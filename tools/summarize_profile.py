@@ -26,7 +26,18 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
-stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)[0]
+def newest(pattern):
+    """One file per directory: a profile repeated under the same tag leaves the earlier run's files beside the new ones
+    (results are merged into the local copy of the directory, never removed from it)."""
+    by_dir = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
+stats = newest(os.path.join(src, "trace", "**", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 kern = {}
 for r in csv.DictReader(open(stats)):
@@ -35,7 +46,7 @@ for r in csv.DictReader(open(stats)):
 
 sums = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(int))
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True)):
+for f in newest(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         if "rrt::" in r["Kernel_Name"]:
             k = short(r["Kernel_Name"])
