@@ -189,7 +189,7 @@ struct DeviceScene {
     rrt::SceneView<double> v64{};
     rrt::LightView<float> l32{};
     rrt::LightView<double> l64{};
-    // One tree per builder (rrt_accel): [0] the radix tree built on the GPU, [1] the surface-area tree built on the
+    // One tree per builder (rrt_accel): [0] the cluster tree built on the GPU, [1] the surface-area tree built on the
     // host.  The kernels read whichever select_tree() put into the views last.
     struct Tree {
         bool built = false;
@@ -447,13 +447,10 @@ struct DevBuf {
 //   area tree, wavefront  8.0    7.8    7.7    7.5    7.3    7.2    7.1    6.8    6.5    6.2    6.2
 const size_t kAutoBvhThreshold = 100;
 const size_t kAutoWavefrontThreshold = 50000;
-// Subtrees of at most this many primitives are folded into one leaf.  A traversal step costs one
-// 64-byte fetch whether it reads a node or a primitive; 2 minimises their sum on triangle meshes.
-const int kBvhLeafMax = 2;
-// The surface-area tree keeps one primitive per leaf: its boxes separate neighbouring triangles well enough that a
-// second primitive per leaf is tested in vain more often than a node step is saved (million-triangle scene, steps per
-// ray node + primitive: 1 -> 13.3 + 3.2, 2 -> 11.9 + 5.4, 3 -> 11.6 + 7.2; radix tree: 1 -> 15.9 + 3.1, 2 -> 15.4 + 3.8).
-const int kSahLeafMax = 1;
+// One primitive per leaf.  A traversal step costs one 64-byte fetch whether it reads a node or a primitive, and with
+// four child boxes per node a second primitive in a leaf is tested in vain more often than a node step is saved
+// (million-triangle scene, node + primitive steps per ray, surface-area tree: 1 -> 13.3 + 3.2, 2 -> 11.9 + 5.4, 3 -> 11.6 + 7.2).
+const int kBvhLeafMax = 1;
 
 float round_down(double x) {
     float f = (float)x;
@@ -477,8 +474,8 @@ void select_tree(DeviceScene* ds, int kind) {
 }
 
 // Builds a tree of a device scene on first use (shared by the f32 and f64 views: boxes are f32) and selects it.
-// kind 0: Morton-code radix tree, built on the GPU (rrt_lbvh.hip); kind 1: binned surface-area heuristic, built by
-// the host's threads (rrt_sah.hpp).  Both end in the same 4-wide quantised nodes and leaf records.
+// kind 0: clustering along the Morton order, built on the GPU (rrt_lbvh.hip, rrt_ploc.hip); kind 1: binned surface-area
+// heuristic, built by the host's threads (rrt_sah.hpp).  Both end in the same 4-wide quantised nodes and leaf records.
 int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) {
     if (ds->tree[kind].built) {
         select_tree(ds, kind);
@@ -563,15 +560,12 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
         ds->allocs.push_back(nodes);
         HIP_TRY(hipMalloc(&slots, sizeof(int32_t) * (size_t)n));
         ds->allocs.push_back(slots);
-        int leaf_max = kind == 1 ? kSahLeafMax : kBvhLeafMax;
-        if (const char* e = getenv("RRT_DEBUG_LEAF_MAX")) leaf_max = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : leaf_max;  // experiments
         std::vector<int32_t> map;  // sorted slot -> index among the bounded primitives
         if (kind == 1) {
             std::vector<rrt::BvhNode> binary;
             const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-            rrt::SahBuilder(lo.data(), hi.data(), n, leaf_max).build(binary, map, threads);
-            static const bool marks = [] { const char* e = getenv("RRT_DEBUG_WIDEN_MARKS"); return e ? atoi(e) != 0 : true; }();  // experiments
-            HIP_TRY(rrt::bvh_widen_host_tree(binary.data(), (int)binary.size(), marks, (rrt::WideNode*)nodes, be->stream));
+            rrt::SahBuilder(lo.data(), hi.data(), n, kBvhLeafMax).build(binary, map, threads);
+            HIP_TRY(rrt::bvh_widen_host_tree(binary.data(), (int)binary.size(), (rrt::WideNode*)nodes, be->stream));
         } else {
             DevBuf dlo, dhi;
             HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));
@@ -580,8 +574,7 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
             HIP_TRY(hipMemcpyAsync(dhi.p, hi.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
             float flo[3], fhi[3];
             for (int k = 0; k < 3; ++k) { flo[k] = round_down(slo[k]); fhi[k] = round_up(shi[k]); }
-            HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, leaf_max, (rrt::WideNode*)nodes,
-                                    (int*)slots, be->stream));
+            HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, (rrt::WideNode*)nodes, (int*)slots, be->stream));
             map.resize((size_t)n);
             HIP_TRY(hipMemcpy(map.data(), slots, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
         }
@@ -617,7 +610,7 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
     return RRT_OK;
 }
 
-// Which tree an rrt_accel value means: -1 none (linear scan), 0 radix tree, 1 surface-area tree.
+// Which tree an rrt_accel value means: -1 none (linear scan), 0 cluster tree (GPU), 1 surface-area tree (host).
 int tree_kind(const rrt_scene* sc, uint32_t accel) {
     if (accel == RRT_ACCEL_LBVH) return 0;
     if (accel == RRT_ACCEL_SAH) return 1;

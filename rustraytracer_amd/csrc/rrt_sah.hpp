@@ -27,6 +27,54 @@ struct SahBox {
     }
 };
 
+#if defined(__HIPCC__)
+#define RRT_SAH_HD __host__ __device__
+#else
+#define RRT_SAH_HD
+#endif
+
+// Which binary nodes every 4-wide node absorbs, chosen for the whole tree at once.  A ray pays one step for every
+// wide node it enters, i.e. for every child box of a wide node that is itself a wide node; with
+//   f(v) = expected steps below v when v is the root of a wide node (box areas as entry probabilities),
+// f(v) = min over the ways to absorb up to two internal descendants connected to v of
+//        the sum, over the internal children the wide node is left with, of (their box area + their f).
+// This is the step for node k: f of its children and grandchildren must be known (any bottom-up order does);
+// the choice goes into BvhNode::pad0 as SAH_OPEN_* bits.  Opening the largest child first, as the widening kernel
+// does on its own, ends 4 % above this on a million-triangle mesh.
+RRT_SAH_HD inline void sah_mark_node(BvhNode* nodes, float* f, size_t k) {
+    BvhNode& N = nodes[k];
+    auto area = [](const BvhNode& P, int w) {
+        const float* l = w ? P.lo1 : P.lo0;
+        const float* h = w ? P.hi1 : P.hi0;
+        const float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    auto link = [](const BvhNode& P, int w) { return w ? P.c1 : P.c0; };
+    auto G = [&](const BvhNode& P, int w) { const int32_t c = link(P, w); return c >= 0 ? area(P, w) + f[(size_t)c] : 0.f; };  // a leaf child costs the same wherever it hangs
+    float best = G(N, 0) + G(N, 1);
+    int32_t shape = 0;
+    auto consider = [&](float cost, int32_t bits) { if (cost < best) { best = cost; shape = bits; } };
+    for (int w = 0; w < 2; ++w) {
+        const int32_t c = link(N, w);
+        if (c < 0) continue;
+        const BvhNode& C = nodes[(size_t)c];
+        const float other = G(N, 1 - w);
+        consider(other + G(C, 0) + G(C, 1), SAH_OPEN_LEFT << w);
+        for (int x = 0; x < 2; ++x) {
+            const int32_t d = link(C, x);
+            if (d < 0) continue;
+            const BvhNode& D = nodes[(size_t)d];
+            consider(other + G(C, 1 - x) + G(D, 0) + G(D, 1), (SAH_OPEN_LEFT << w) | (SAH_OPEN_LEFT_0 << (2 * w + x)));
+        }
+    }
+    if (N.c0 >= 0 && N.c1 >= 0) {
+        const BvhNode &L = nodes[(size_t)N.c0], &R = nodes[(size_t)N.c1];
+        consider(G(L, 0) + G(L, 1) + G(R, 0) + G(R, 1), SAH_OPEN_LEFT | SAH_OPEN_RIGHT);
+    }
+    f[k] = best;
+    N.pad0 = shape;
+}
+
 class SahBuilder {
 public:
 #ifndef RRT_SAH_BINS
@@ -85,50 +133,10 @@ public:
         mark_wide_nodes(nodes);
     }
 
-    // Which binary nodes every 4-wide node absorbs, chosen for the whole tree at once.  A ray pays one step for every
-    // wide node it enters, i.e. for every child box of a wide node that is itself a wide node; with
-    //   f(v) = expected steps below v when v is the root of a wide node (box areas as entry probabilities),
-    // f(v) = min over the ways to absorb up to two internal descendants connected to v of
-    //        the sum, over the internal children the wide node is left with, of (their box area + their f).
-    // Children have larger indices than their parents, so one backward pass computes f; the choice goes into
-    // BvhNode::pad0 as SAH_OPEN_* bits (opening the largest child first, as the widening kernel does on its own,
-    // ends 4 % above this on a million-triangle mesh).
+    // Marks every node of a tree whose children have larger indices than their parents (see sah_mark_node).
     static void mark_wide_nodes(std::vector<BvhNode>& nodes) {
-        const size_t m = nodes.size();
-        std::vector<float> f(m, 0.f);
-        auto area = [](const BvhNode& N, int w) {
-            const float* l = w ? N.lo1 : N.lo0;
-            const float* h = w ? N.hi1 : N.hi0;
-            const float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
-            return dx * dy + dy * dz + dz * dx;
-        };
-        for (size_t k = m; k-- > 0;) {
-            BvhNode& N = nodes[k];
-            auto link = [&](const BvhNode& P, int w) { return w ? P.c1 : P.c0; };
-            auto G = [&](const BvhNode& P, int w) { const int32_t c = link(P, w); return c >= 0 ? area(P, w) + f[(size_t)c] : 0.f; };  // a leaf child costs the same wherever it hangs
-            float best = G(N, 0) + G(N, 1);
-            int32_t shape = 0;
-            auto consider = [&](float cost, int32_t bits) { if (cost < best) { best = cost; shape = bits; } };
-            for (int w = 0; w < 2; ++w) {
-                const int32_t c = link(N, w);
-                if (c < 0) continue;
-                const BvhNode& C = nodes[(size_t)c];
-                const float other = G(N, 1 - w);
-                consider(other + G(C, 0) + G(C, 1), SAH_OPEN_LEFT << w);
-                for (int x = 0; x < 2; ++x) {
-                    const int32_t d = link(C, x);
-                    if (d < 0) continue;
-                    const BvhNode& D = nodes[(size_t)d];
-                    consider(other + G(C, 1 - x) + G(D, 0) + G(D, 1), (SAH_OPEN_LEFT << w) | (SAH_OPEN_LEFT_0 << (2 * w + x)));
-                }
-            }
-            if (N.c0 >= 0 && N.c1 >= 0) {
-                const BvhNode &L = nodes[(size_t)N.c0], &R = nodes[(size_t)N.c1];
-                consider(G(L, 0) + G(L, 1) + G(R, 0) + G(R, 1), SAH_OPEN_LEFT | SAH_OPEN_RIGHT);
-            }
-            f[k] = best;
-            N.pad0 = shape;
-        }
+        std::vector<float> f(nodes.size(), 0.f);
+        for (size_t k = nodes.size(); k-- > 0;) sah_mark_node(nodes.data(), f.data(), k);
     }
 
 private:

@@ -23,7 +23,7 @@ for n in sizes:
         for rep in range(2):
             rgb, st = be.render_accumulate(sc, rc.render_desc(accel=accel, pipeline=pipe))
         row.append(st["rays"] / st["kernel_ms"] / 1e3)
-    print("prims %7d  linear/fused %8.0f  radix tree fused %8.0f wavefront %8.0f  surface-area tree fused %8.0f wavefront %8.0f Mrays/s"
+    print("prims %7d  linear/fused %8.0f  cluster tree fused %8.0f wavefront %8.0f  surface-area tree fused %8.0f wavefront %8.0f Mrays/s"
           % (flat.n_prims, *row), flush=True)
 if large:
     import make_c5_assets
@@ -37,5 +37,5 @@ if large:
             for rep in range(2):
                 rgb, st = be.render_accumulate(sc, rc.render_desc(accel=accel, pipeline=pipe))
             row.append(st["rays"] / st["kernel_ms"] / 1e3)
-    print("mesh_1m %7d prims  radix tree fused %8.0f wavefront %8.0f  surface-area tree fused %8.0f wavefront %8.0f Mrays/s"
+    print("mesh_1m %7d prims  cluster tree fused %8.0f wavefront %8.0f  surface-area tree fused %8.0f wavefront %8.0f Mrays/s"
           % (flat.n_prims, *row), flush=True)

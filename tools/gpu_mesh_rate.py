@@ -9,7 +9,7 @@ n = int(sys.argv[1]); reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 be = api.Backend(0)
 sc = api.Scene(T.mesh_scene(n))
 rc = config.stratified_config(1024, 1024, 16, 16)
-for name, accel in (("radix", api.ACCEL_LBVH), ("area", api.ACCEL_SAH)):
+for name, accel in (("cluster", api.ACCEL_LBVH), ("area", api.ACCEL_SAH)):
     out = []
     for rep in range(reps):
         rgb, st = be.render_accumulate(sc, rc.render_desc(accel=accel, pipeline=api.PIPELINE_WAVEFRONT))
