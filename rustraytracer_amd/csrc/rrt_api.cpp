@@ -439,12 +439,12 @@ struct DevBuf {
 // Scenes with more primitives than this get the surface-area tree under RRT_ACCEL_AUTO, and tree scenes with more
 // primitives than kAutoWavefrontThreshold the wavefront pipeline under RRT_PIPELINE_AUTO.  Measured on
 // triangle meshes at 1024x1024 @ 256 spp (tools/gpu_crossover.py), Grays/s:
-//   primitives             26     50     92    184    382    758   1484   5854  23718  99858  399426
-//   scan, fused          41.8   26.9   16.2    8.6    4.3    2.2    1.2    0.3
-//   radix tree, fused    24.5   17.3   14.4   12.8   12.0   10.6    9.4    8.0    6.6    5.5    4.5
-//   radix tree, wavefront 8.0    7.7    7.3    7.2    7.1    6.9    6.8    6.6    6.2    6.0    5.9
-//   area tree, fused     23.5   19.7   17.0   14.7   12.6   11.3   10.6    8.7    7.2    5.9    4.7
-//   area tree, wavefront  8.0    7.8    7.7    7.5    7.3    7.2    7.1    6.8    6.5    6.2    6.2
+//   primitives               26     50     92    184    382    758   1484   5854  23718  99858  399426
+//   scan, fused            42.5   26.6   16.4    8.8    4.3    2.2    1.1    0.3
+//   cluster tree, fused    22.5   19.3   16.3   14.4   12.6   11.3   10.0    8.4    6.9    5.4    4.6
+//   cluster tree, wavefront 7.6    7.8    7.6    7.5    7.3    7.1    6.9    6.6    6.3    5.9    5.8
+//   area tree, fused       22.8   19.8   17.2   14.6   12.7   11.4   10.8    8.7    7.5    6.0    4.9
+//   area tree, wavefront    7.7    7.8    7.6    7.5    7.3    7.2    7.1    6.8    6.5    6.2    6.2
 const size_t kAutoBvhThreshold = 100;
 const size_t kAutoWavefrontThreshold = 50000;
 // One primitive per leaf.  A traversal step costs one 64-byte fetch whether it reads a node or a primitive, and with
