@@ -81,6 +81,13 @@ ploc_nearest_kernel(const Cluster* __restrict__ c, int m, int* __restrict__ near
     nearest[i] = best_j;
 }
 
+// A round that pairs neighbours by position alone (2k with 2k + 1): see ploc_build.
+__global__ void __launch_bounds__(PLOC_BLOCK) ploc_pair_kernel(int m, int* __restrict__ nearest) {
+    const int i = blockIdx.x * PLOC_BLOCK + threadIdx.x;
+    if (i >= m) return;
+    nearest[i] = (i ^ 1) < m ? (i ^ 1) : -1;
+}
+
 // flags[i] = (cluster i survives the round) | (cluster i is the lower one of a merging pair) << 32
 __global__ void __launch_bounds__(PLOC_BLOCK)
 ploc_flag_kernel(const int* __restrict__ nearest, int m, unsigned long long* __restrict__ flags) {
@@ -155,9 +162,15 @@ hipError_t ploc_build(const float* d_lo, const float* d_hi, const int* d_prim_of
     hipLaunchKernelGGL(ploc_init_kernel, grid(n), dim3(PLOC_BLOCK), 0, stream, d_lo, d_hi, d_prim_of_slot, n, a);
     PLOC_TRY(hipGetLastError());
     int m = n, first_node = n - 2;
+    // Every round merges at least the globally cheapest pair, and on meshes a third of the clusters; an input on which
+    // every cluster prefers the same side (boxes growing along the order) would merge one pair per round.  A round that
+    // merges fewer than 1/32 of the clusters is therefore followed by one that pairs neighbours by position, which halves
+    // the count whatever the boxes are: at most ~450 rounds for 2^28 primitives.
+    bool pair_by_position = false;
     for (int round = 0; m > 1; ++round) {
-        if (round > 64 * 32) PLOC_TRY(hipErrorUnknown);  // every round merges at least the globally cheapest pair
-        hipLaunchKernelGGL(ploc_nearest_kernel, grid(m), dim3(PLOC_BLOCK), 0, stream, a, m, nearest);
+        if (round > 4096) PLOC_TRY(hipErrorUnknown);
+        if (pair_by_position) hipLaunchKernelGGL(ploc_pair_kernel, grid(m), dim3(PLOC_BLOCK), 0, stream, m, nearest);
+        else hipLaunchKernelGGL(ploc_nearest_kernel, grid(m), dim3(PLOC_BLOCK), 0, stream, a, m, nearest);
         PLOC_TRY(hipGetLastError());
         hipLaunchKernelGGL(ploc_flag_kernel, grid(m), dim3(PLOC_BLOCK), 0, stream, nearest, m, flags);
         PLOC_TRY(hipGetLastError());
@@ -172,6 +185,7 @@ hipError_t ploc_build(const float* d_lo, const float* d_hi, const int* d_prim_of
         if (merged < 1 || kept != m - merged) PLOC_TRY(hipErrorUnknown);
         hipLaunchKernelGGL(ploc_mark_kernel, grid(merged), dim3(PLOC_BLOCK), 0, stream, d_nodes, f, first_node - merged + 1, merged);
         PLOC_TRY(hipGetLastError());
+        pair_by_position = !pair_by_position && m > 64 && merged < m / 32;
         first_node -= merged;
         m = kept;
         Cluster* t = a; a = b; b = t;

@@ -216,6 +216,44 @@ def test_lbvh_edge_cases(gpu, case):
         assert a[1]["rays"] == b[1]["rays"] == c[1]["rays"] and a[1]["bounces"] == b[1]["bounces"] == c[1]["bounces"]
 
 
+def test_boxes_growing_along_a_line(gpu):
+    """Triangles whose size and spacing grow geometrically along x: every cluster of the GPU builder prefers its left
+    neighbour, so only one pair per round would merge by cost alone (the builder then pairs by position); both trees
+    must still be built quickly and agree with the scan."""
+    import time
+    api, be = gpu
+    n = 20000
+    x = 1.0005 ** np.arange(n)  # 1 .. 22000
+    s = 2e-4 * x
+    prims = []
+    tri = np.zeros((n, 3, 3))
+    tri[:, 0] = np.stack([x, -s, -s - 5], axis=1)
+    tri[:, 1] = np.stack([x + s, s, -5 + 0 * x], axis=1)
+    tri[:, 2] = np.stack([x - s, s, s - 5], axis=1)
+    p = np.zeros(n, dtype=_abi.PRIM_DTYPE)
+    p["type"] = _abi.PRIM_TRIANGLE
+    p["prim_id"] = np.arange(n)
+    p["v"][:, :9] = tri.reshape(n, 9)
+    m = np.zeros(1, dtype=_abi.MATERIAL_DTYPE)
+    m["type"], m["rgb"] = _abi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5)
+    from rustraytracer_amd import config
+    flat = config.FlatScene(config.perspective_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 50.0, 1.0), p, m)
+    sc = api.Scene(flat)
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, n, 4000)
+    target = tri[k].mean(axis=1) + rng.normal(size=(4000, 3)) * s[k, None] * 0.5
+    o = target + np.array([0.0, 0.0, 3.0]) + rng.normal(size=(4000, 3)) * 0.3
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    lin = be.intersect(sc, o, d, accel=api.ACCEL_LINEAR)
+    assert (lin[0] >= 0).sum() > 500
+    for tree in TREES:
+        t0 = time.time()
+        got = be.intersect(sc, o, d, accel=tree)
+        assert time.time() - t0 < 10.0, tree
+        assert _same(lin, got), tree
+
+
 def test_empty_scene(gpu, cfg):
     api, be = gpu
     sc = api.Scene(S.make_scene([], []))
