@@ -40,7 +40,13 @@ __device__ __forceinline__ float union_area(const Cluster& a, const Cluster& b) 
     const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
     const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
     const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
-    return dx * dy + dy * dz + dz * dx;
+    const float u = dx * dy + dy * dz + dz * dx;
+#ifdef RRT_EXP_PLOC_RATIO  // experiment: union area squared over the sum of the two areas
+    auto area = [](const Cluster& c) { const float x = c.hi[0] - c.lo[0], y = c.hi[1] - c.lo[1], z = c.hi[2] - c.lo[2]; return x * y + y * z + z * x; };
+    return u * u / fmaxf(area(a) + area(b), 1e-30f);
+#else
+    return u;
+#endif
 }
 
 __global__ void __launch_bounds__(PLOC_BLOCK)
