@@ -72,7 +72,7 @@ typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_
  *         smallest box merge first); ~0.45 s per million primitives including the upload;
  *   SAH   binned surface-area-heuristic tree built top-down by up to 16 host threads (~0.5 s per million
  *         primitives), about a tenth fewer traversal steps per ray.
- * AUTO = LINEAR for scenes of up to 100 primitives (where it is the fastest), SAH otherwise.  A scene keeps every
+ * AUTO = LINEAR for scenes of up to 72 primitives (where it is the fastest), SAH otherwise.  A scene keeps every
  * tree it was asked for (per device) until rrt_scene_destroy. */
 typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2, RRT_ACCEL_SAH = 3 } rrt_accel;
 

@@ -272,7 +272,8 @@ RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, 
                 const uint4* rec = reinterpret_cast<const uint4*>(sv.nodes + w.node);
                 walk_node(w, s_stack, spill, rec[0], rec[1], rec[2], rec[3]);
                 hc.node_tests += 1;
-            } else {
+            }
+            if (w.node < 0 && w.node != BVH_DONE) {  // (in the same trip as the node step that led here)
                 const int v = ~w.node;
                 const int slot = v & BVH_SLOT_MASK, left = v >> BVH_SLOT_BITS;
                 leaf_test<R>(sv, sv.leaves + slot, w.o, w.d, w.acc);
