@@ -131,6 +131,49 @@ public:
             }
         }
         mark_wide_nodes(nodes);
+        order_top(nodes, 4096);
+    }
+
+    // Renumbers the nodes so that the `top` most probably entered ones (largest boxes first, from the root down) come
+    // first, in that order; the others keep their relative order behind them.  Children still have larger numbers than
+    // their parents.  The traversal kernels keep the first wide nodes of the array in LDS, and the hot top of the tree
+    // shares cache lines.
+    static void order_top(std::vector<BvhNode>& nodes, size_t top) {
+        const size_t m = nodes.size();
+        if (m < 3) return;
+        top = std::min(top, m);
+        std::vector<int32_t> new_id(m, -1);
+        auto area = [](const BvhNode& N, int w) {
+            const float* l = w ? N.lo1 : N.lo0;
+            const float* h = w ? N.hi1 : N.hi0;
+            const float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        std::vector<std::pair<float, int32_t>> heap;  // (box area, node), largest area on top; ties: the lower number
+        auto less = [](const std::pair<float, int32_t>& a, const std::pair<float, int32_t>& b) {
+            return a.first < b.first || (a.first == b.first && a.second > b.second);
+        };
+        heap.push_back({3.0e38f, 0});
+        size_t next = 0;
+        while (next < top && !heap.empty()) {
+            std::pop_heap(heap.begin(), heap.end(), less);
+            const int32_t v = heap.back().second;
+            heap.pop_back();
+            new_id[(size_t)v] = (int32_t)next++;
+            const BvhNode& N = nodes[(size_t)v];
+            if (N.c0 >= 0) { heap.push_back({area(N, 0), N.c0}); std::push_heap(heap.begin(), heap.end(), less); }
+            if (N.c1 >= 0) { heap.push_back({area(N, 1), N.c1}); std::push_heap(heap.begin(), heap.end(), less); }
+        }
+        for (size_t i = 0; i < m; ++i)
+            if (new_id[i] < 0) new_id[i] = (int32_t)next++;
+        std::vector<BvhNode> out(m);
+        for (size_t i = 0; i < m; ++i) {
+            BvhNode N = nodes[i];
+            if (N.c0 >= 0) N.c0 = new_id[(size_t)N.c0];
+            if (N.c1 >= 0) N.c1 = new_id[(size_t)N.c1];
+            out[(size_t)new_id[i]] = N;
+        }
+        nodes.swap(out);
     }
 
     // Marks every node of a tree whose children have larger indices than their parents (see sah_mark_node).

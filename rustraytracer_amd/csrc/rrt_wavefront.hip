@@ -102,14 +102,28 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
 // WF_REFILL_MIN lanes are idle.
 constexpr int WF_REFILL_MIN = 20;  // (64 Mi-path queues, million-triangle scene; radix tree: 8 -> 5.80, 12 -> 5.95, 16 -> 6.00, 20 -> 5.99 Grays/s; surface-area tree: 16 -> 6.36, 20 -> 6.40, 24 -> 6.30)
 
+#ifndef RRT_WF_STACK_LEVELS
+#define RRT_WF_STACK_LEVELS 12  // levels of the node stack in LDS (1 KB per level and block), deeper ones in private memory
+#endif
+#ifndef RRT_WF_TOP_NODES
+#define RRT_WF_TOP_NODES 120    // wide nodes kept in LDS (64 B each)
+#endif
+constexpr int WF_STACK_LEVELS = RRT_WF_STACK_LEVELS;
 #ifndef RRT_EXP_TREE_WAVES
 #define RRT_EXP_TREE_WAVES 8  // experiment: waves per SIMD the tree kernel is compiled for
 #endif
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(RRT_EXP_TREE_WAVES)))
 wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min) {
     typedef float R;
-    __shared__ TreeStackLds s_stack;
+    __shared__ int s_stack[WF_STACK_LEVELS][BVH_BLOCK];
     __shared__ BlockCounters s_ctr;
+#if RRT_WF_TOP_NODES > 0
+    // The first wide nodes of the array are the top of the tree (both builders number top-down): every ray's first
+    // few steps read them, from LDS here instead of through the vector memory path.
+    __shared__ uint4 s_top[RRT_WF_TOP_NODES][4];
+    const int top_n = sv.n_bvh_prims - 1 < RRT_WF_TOP_NODES ? sv.n_bvh_prims - 1 : RRT_WF_TOP_NODES;
+    for (int t = threadIdx.x; t < top_n * 4; t += BVH_BLOCK) s_top[t >> 2][t & 3] = reinterpret_cast<const uint4*>(sv.nodes)[t];
+#endif
     const uint32_t n_in = wp.ctl->count[parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         wp.ctl->count[parity ^ 1] = 0;
@@ -148,7 +162,7 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
     uint32_t off = 0;
     const WfQueue& q = wp.q[parity];
 
-    TreeStackSpill spill;
+    int spill[3 * 48 - WF_STACK_LEVELS];  // (see TreeStackSpill)
     TreeWalk<R> w;
     w.o = mk<R>(0, 0, 0);
     w.d = w.inv_d = mk<R>(0, 0, 1);
@@ -158,6 +172,19 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
     HitCounters hc{0, 0};
     uint32_t mine = 0;
     bool have = false;
+    auto push = [&](int node) {
+        if (w.sp < WF_STACK_LEVELS) s_stack[w.sp][threadIdx.x] = node;
+        else spill[w.sp - WF_STACK_LEVELS] = node;
+        w.sp += 1;
+    };
+    auto pop = [&]() {
+        if (w.sp == 0) {
+            w.node = BVH_DONE;
+            return;
+        }
+        w.sp -= 1;
+        w.node = w.sp < WF_STACK_LEVELS ? s_stack[w.sp][threadIdx.x] : spill[w.sp - WF_STACK_LEVELS];
+    };
 #ifdef RRT_EXP_TREE_STATS  // experiment: one wave in 509 blocks prints how its lanes were occupied (lanes with work, lanes at a node, refills)
     uint32_t st_trips = 0, st_work = 0, st_node = 0, st_refill = 0, st_refill_idle = 0, st_mixed = 0;
 #endif
@@ -213,8 +240,16 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
         // the four 16-byte loads between the two kinds of record, a sixth of the lanes stood at a leaf in every trip).
         if (__ballot(w.node >= 0) != 0ull) {
             if (w.node >= 0) {
-                const uint4* rec = reinterpret_cast<const uint4*>(sv.nodes + w.node);
-                const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                uint4 q0, q1, q2, q3;
+#if RRT_WF_TOP_NODES > 0
+                if (w.node < top_n) {
+                    q0 = s_top[w.node][0]; q1 = s_top[w.node][1]; q2 = s_top[w.node][2]; q3 = s_top[w.node][3];
+                } else
+#endif
+                {
+                    const uint4* rec = reinterpret_cast<const uint4*>(sv.nodes + w.node);
+                    q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+                }
 #ifdef RRT_EXP_EXTRA_VALU
                 {  // sensitivity experiment: extra dependent FMAs per node step
                     float x = __uint_as_float(q0.x);
@@ -223,7 +258,10 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                     if (x == 12345.678f) hc.node_tests += 1;
                 }
 #endif
-                walk_node(w, s_stack, spill, q0, q1, q2, q3);
+                R dist[4];
+                int child[4];
+                node_children(w, q0, q1, q2, q3, dist, child);
+                node_descend(w, dist, child, push, pop);
                 hc.node_tests += 1;
             }
         }
@@ -237,7 +275,7 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                 hc.prim_tests += 1;
                 const int left = v >> BVH_SLOT_BITS;
                 if (left > 0) w.node = ~((slot + 1) | ((left - 1) << BVH_SLOT_BITS));
-                else walk_pop(w, s_stack, spill);
+                else pop();
             }
         }
     }
