@@ -256,7 +256,7 @@ def run_rank(args):
         raise SystemExit("rank %d of %d has no sample index of %d spp" % (rank, world, rc.spp))
 
     use_tree = flat.n_prims > 72
-    wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and flat.n_prims > 50000 and args.precision == "f32")
+    wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and flat.n_prims > 150000 and args.precision == "f32")
     if plumbing:
         acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32)
 

@@ -440,13 +440,13 @@ struct DevBuf {
 // primitives than kAutoWavefrontThreshold the wavefront pipeline under RRT_PIPELINE_AUTO.  Measured on
 // triangle meshes at 1024x1024 @ 256 spp (tools/gpu_crossover.py), Grays/s:
 //   primitives               26     50     92    184    382    758   1484   5854  23718  99858  399426
-//   scan, fused            42.4   27.2   16.4    8.8    4.3    2.2    1.2    0.3
-//   cluster tree, fused    24.5   21.6   17.9   16.1   14.0   12.5   11.0    9.1    7.3    5.9    4.7
-//   cluster tree, wavefront 8.0    8.0    7.9    7.7    7.5    7.4    7.1    6.8    6.5    6.1    5.8
-//   area tree, fused       25.1   21.5   19.0   16.1   14.3   12.8   11.9    9.4    7.9    6.0    5.3
-//   area tree, wavefront    8.1    8.0    7.9    7.7    7.6    7.4    7.4    7.0    6.7    6.3    6.0
+//   scan, fused            42.4   27.3   16.3    8.7    4.3    2.2    1.1    0.3
+//   cluster tree, fused    25.7   22.4   19.4   16.9   14.6   12.9   11.2    9.3    7.8    6.0    4.8
+//   cluster tree, wavefront 8.1    8.0    7.9    7.8    7.6    7.3    7.1    6.8    6.4    6.1    6.1
+//   area tree, fused       25.9   22.0   19.6   16.9   15.0   12.8   12.2    9.9    8.2    6.5    5.4
+//   area tree, wavefront    8.1    8.1    8.0    7.8    7.6    7.4    7.4    7.0    6.6    6.4    6.4   (1 M triangles: 6.2 against 3.7 fused)
 const size_t kAutoBvhThreshold = 72;
-const size_t kAutoWavefrontThreshold = 50000;
+const size_t kAutoWavefrontThreshold = 150000;
 // One primitive per leaf.  A traversal step costs one 64-byte fetch whether it reads a node or a primitive, and with
 // four child boxes per node a second primitive in a leaf is tested in vain more often than a node step is saved
 // (million-triangle scene, node + primitive steps per ray, surface-area tree: 1 -> 13.3 + 3.2, 2 -> 11.9 + 5.4, 3 -> 11.6 + 7.2).

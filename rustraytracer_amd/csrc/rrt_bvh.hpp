@@ -49,7 +49,7 @@ RRT_DEV int hit_winner(const HitAcc<R>& h) {
 // i.e. 48 wide levels.  Entries carry no distance: a stale entry costs one node fetch whose children
 // all fail, which happens for ~5 % of the nodes, and half the bytes per entry keep twice as many
 // levels in LDS at full occupancy.
-constexpr int BVH_LDS_LEVELS = 16;
+constexpr int BVH_LDS_LEVELS = 12;
 constexpr int BVH_SPILL_LEVELS = 3 * 48 - BVH_LDS_LEVELS;
 constexpr int BVH_BLOCK = 256;  // every kernel that traverses the tree runs 256-thread blocks
 constexpr int BVH_DONE = BVH_NO_CHILD;
@@ -57,6 +57,39 @@ constexpr int BVH_DONE = BVH_NO_CHILD;
 struct TreeStackLds {
     int node[BVH_LDS_LEVELS][BVH_BLOCK];
 };
+// The first BVH_TOP_NODES wide nodes of the array -- the top of the tree, both builders number top-down -- are kept in
+// LDS by every kernel that walks the tree: a ray's first few node steps (all of them in a tree of a few hundred
+// primitives) then read LDS instead of going through the vector memory path.  7.5 KB per block; the node stack keeps 12
+// levels in LDS beside it (16 without it made no difference).  tree_top_load() is called by all threads of a block once,
+// before the first walk.
+constexpr int BVH_TOP_NODES = 120;
+struct TreeTopLds {
+    uint4 q[BVH_TOP_NODES][4];
+};
+static __shared__ TreeTopLds g_tree_top;
+
+template <typename R>
+RRT_DEV int tree_top_count(const SceneView<R>& sv) {
+    return sv.n_bvh_prims - 1 < BVH_TOP_NODES ? sv.n_bvh_prims - 1 : BVH_TOP_NODES;  // (<= 0: no nodes)
+}
+
+template <typename R>
+RRT_DEV void tree_top_load(const SceneView<R>& sv) {
+    const int top_n = tree_top_count(sv);
+    for (int t = threadIdx.x; t < top_n * 4; t += BVH_BLOCK) g_tree_top.q[t >> 2][t & 3] = reinterpret_cast<const uint4*>(sv.nodes)[t];
+    __syncthreads();
+}
+
+// The four 16-byte words of wide node `node`.
+template <typename R>
+RRT_DEV void tree_node_words(const SceneView<R>& sv, int node, int top_n, uint4& q0, uint4& q1, uint4& q2, uint4& q3) {
+    if (node < top_n) {
+        q0 = g_tree_top.q[node][0]; q1 = g_tree_top.q[node][1]; q2 = g_tree_top.q[node][2]; q3 = g_tree_top.q[node][3];
+    } else {
+        const uint4* rec = reinterpret_cast<const uint4*>(sv.nodes + node);
+        q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+    }
+}
 // The private part of the stack is a separate local array in every kernel (a struct with a
 // dynamically indexed member would live in private memory as a whole).
 typedef int TreeStackSpill[BVH_SPILL_LEVELS];
@@ -267,10 +300,12 @@ RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, 
         hc.prim_tests += 1;
     } else if (sv.n_bvh_prims > 1) {
         walk_start(w, o, d);
+        const int top_n = tree_top_count(sv);
         while (w.node != BVH_DONE) {
             if (w.node >= 0) {
-                const uint4* rec = reinterpret_cast<const uint4*>(sv.nodes + w.node);
-                walk_node(w, s_stack, spill, rec[0], rec[1], rec[2], rec[3]);
+                uint4 q0, q1, q2, q3;
+                tree_node_words(sv, w.node, top_n, q0, q1, q2, q3);
+                walk_node(w, s_stack, spill, q0, q1, q2, q3);
                 hc.node_tests += 1;
             }
             if (w.node < 0 && w.node != BVH_DONE) {  // (in the same trip as the node step that led here)

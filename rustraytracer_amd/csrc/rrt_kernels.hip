@@ -36,6 +36,7 @@ intersect_kernel(SceneView<R> sv, size_t n, const double* __restrict__ a, const 
     }
     HitCounters hc{0, 0};
     R t;
+    if (BVH) tree_top_load(sv);
     int g = closest_hit<R, BVH>(sv, o, d, t, hc);
     if (i < n) {
         if (g >= 0) {
@@ -92,6 +93,7 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
         for (int i = threadIdx.x; i < sv.n_objects; i += 256) s_mats[i] = sv.mats[i];
         __syncthreads();
     }
+    if (BVH) tree_top_load(sv);
     const uint32_t lane = threadIdx.x & 63u;
     // The kernel wants more scalar registers than a wave has (scene view, render parameters, 24 for a
     // pair of primitive records, wave-uniform counters); what does not fit is parked in lanes of a

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
     if (blockIdx.x * (uint32_t)WF_HIT_BLOCK >= n_in) return;
     if (BVH) {
         if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
-        __syncthreads();
+        tree_top_load(sv);
     }
     const WfQueue& q = wp.q[parity];
     const uint32_t idx = blockIdx.x * (uint32_t)WF_HIT_BLOCK + threadIdx.x;
@@ -102,13 +102,7 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
 // WF_REFILL_MIN lanes are idle.
 constexpr int WF_REFILL_MIN = 20;  // (64 Mi-path queues, million-triangle scene; radix tree: 8 -> 5.80, 12 -> 5.95, 16 -> 6.00, 20 -> 5.99 Grays/s; surface-area tree: 16 -> 6.36, 20 -> 6.40, 24 -> 6.30)
 
-#ifndef RRT_WF_STACK_LEVELS
-#define RRT_WF_STACK_LEVELS 12  // levels of the node stack in LDS (1 KB per level and block), deeper ones in private memory
-#endif
-#ifndef RRT_WF_TOP_NODES
-#define RRT_WF_TOP_NODES 120    // wide nodes kept in LDS (64 B each)
-#endif
-constexpr int WF_STACK_LEVELS = RRT_WF_STACK_LEVELS;
+constexpr int WF_STACK_LEVELS = BVH_LDS_LEVELS;
 #ifndef RRT_EXP_TREE_WAVES
 #define RRT_EXP_TREE_WAVES 8  // experiment: waves per SIMD the tree kernel is compiled for
 #endif
@@ -117,13 +111,8 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
     typedef float R;
     __shared__ int s_stack[WF_STACK_LEVELS][BVH_BLOCK];
     __shared__ BlockCounters s_ctr;
-#if RRT_WF_TOP_NODES > 0
-    // The first wide nodes of the array are the top of the tree (both builders number top-down): every ray's first
-    // few steps read them, from LDS here instead of through the vector memory path.
-    __shared__ uint4 s_top[RRT_WF_TOP_NODES][4];
-    const int top_n = sv.n_bvh_prims - 1 < RRT_WF_TOP_NODES ? sv.n_bvh_prims - 1 : RRT_WF_TOP_NODES;
-    for (int t = threadIdx.x; t < top_n * 4; t += BVH_BLOCK) s_top[t >> 2][t & 3] = reinterpret_cast<const uint4*>(sv.nodes)[t];
-#endif
+    tree_top_load(sv);
+    const int top_n = tree_top_count(sv);
     const uint32_t n_in = wp.ctl->count[parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         wp.ctl->count[parity ^ 1] = 0;
@@ -241,15 +230,7 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
         if (__ballot(w.node >= 0) != 0ull) {
             if (w.node >= 0) {
                 uint4 q0, q1, q2, q3;
-#if RRT_WF_TOP_NODES > 0
-                if (w.node < top_n) {
-                    q0 = s_top[w.node][0]; q1 = s_top[w.node][1]; q2 = s_top[w.node][2]; q3 = s_top[w.node][3];
-                } else
-#endif
-                {
-                    const uint4* rec = reinterpret_cast<const uint4*>(sv.nodes + w.node);
-                    q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
-                }
+                tree_node_words(sv, w.node, top_n, q0, q1, q2, q3);
 #ifdef RRT_EXP_EXTRA_VALU
                 {  // sensitivity experiment: extra dependent FMAs per node step
                     float x = __uint_as_float(q0.x);
