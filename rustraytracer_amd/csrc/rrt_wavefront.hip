@@ -118,15 +118,18 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
         wp.ctl->count[parity ^ 1] = 0;
         wp.ctl->rays += n_in;
     }
-    // Which blocks of 64 rays this wave walks.  The first three quarters of the queue are dealt out
-    // statically (wave w takes blocks w, w + n_waves, ...: no shared counter); the last quarter is
-    // handed out block by block through an atomic counter, so that waves whose rays happened to be
-    // cheap help the others finish instead of idling (a third of the wave slots stood empty at the
-    // end of every trip with the static deal alone).
+    // Which blocks of 64 rays this wave walks.  Nearly all of the queue is dealt out statically (wave w takes blocks
+    // w, w + n_waves, ...: no shared counter); the last 1/64 is handed out block by block through an atomic counter, so
+    // that waves whose rays happened to be cheap help the others finish.  Every dynamic block costs its wave the round
+    // trip of the atomic (a tenth of the time it spends on the block's rays): a quarter of the queue handed out this
+    // way, which paid while the kernel was slower, cost 4 % at the end (1/8: 2 % less, 1/64 = none at all).
     const uint32_t n_ray_blocks = (n_in + 63u) / 64u;
     if (blockIdx.x * (uint32_t)(BVH_BLOCK / 64) >= n_ray_blocks) return;  // more waves than blocks of rays
     const uint32_t stride = gridDim.x * (BVH_BLOCK / 64);
-    const uint32_t static_end = (n_ray_blocks - n_ray_blocks / 4u) / stride * stride;
+#ifndef RRT_EXP_DYNAMIC_SHARE
+#define RRT_EXP_DYNAMIC_SHARE 64u  // 1 / this share of a trip's blocks is handed out dynamically
+#endif
+    const uint32_t static_end = (n_ray_blocks - n_ray_blocks / RRT_EXP_DYNAMIC_SHARE) / stride * stride;
     if (blockIdx.x == 0 && threadIdx.x == 0) wp.ctl->dyn[parity ^ 1] = 0;  // the next trip's counter
     uint32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (BVH_BLOCK / 64) + (threadIdx.x >> 6));
     bool dynamic = false;
