@@ -801,9 +801,11 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc, uint64_t lanes
 // 11.2 at 16 Mi).  Tree scenes: the persistent traversal kernel ends every trip with waves that drain their last
 // block of 64 rays at a fifth of their lanes, ~100 loop trips out of the ~700 a wave makes per 16 Mi rays; with 64 Mi
 // paths (7.5 GB of the 288 GB) that tail is a quarter as large: 5.15 -> 5.60 Grays/s on the million-triangle scene
-// (128 Mi and 256 Mi: 5.62, 5.63).  A device with less free memory gets smaller queues.
+// (128 Mi and 256 Mi: 5.62, 5.63 then).  With the traversal kernel a third faster since, the fixed costs of a trip weigh
+// more: 64 Mi -> 7.50, 128 Mi -> 7.60, 256 Mi -> 7.53 Grays/s; 128 Mi paths are 15 GB of the 288 GB.  A device with less
+// free memory gets smaller queues.
 const uint32_t kWfCapacityLinear = 1u << 24;
-const uint32_t kWfCapacityTree = 1u << 26;
+const uint32_t kWfCapacityTree = 1u << 27;
 const uint32_t kWfCapacityFloor = 1u << 20;
 
 size_t wavefront_bytes(size_t n) {
