@@ -902,7 +902,7 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
         for (uint64_t trip = 0;; ++trip) {
             HIP_TRY(rrt::wf_launch_shade(sv, rp, wp, parity, be->stream));
             parity ^= 1;
-            HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, be->n_cu * 8, be->stream));
+            HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, be->n_cu, be->stream));
             if (trip >= sure && (trip - sure) % check_every == 0) {
                 HIP_TRY(hipMemcpyAsync(&ctl, wp.ctl, sizeof(ctl), hipMemcpyDeviceToHost, be->stream));
                 HIP_TRY(hipStreamSynchronize(be->stream));

@@ -475,11 +475,19 @@ hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_
 }
 
 hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity,
-                                 int persistent_blocks, hipStream_t stream) {
+                                 int n_cu, hipStream_t stream) {
     const dim3 grid(wp.capacity / (uint32_t)WF_HIT_BLOCK), block(WF_HIT_BLOCK);
     if (bvh && sv.n_bvh_prims >= 2) {
         // persistent waves: as many blocks as the device holds at once, never more than there are rays
-        const uint32_t want = grid.x < (uint32_t)persistent_blocks ? grid.x : (uint32_t)persistent_blocks;
+        // as many blocks as the device really holds at once (8 per CU with the kernel's registers and LDS; a block more
+        // than fits would run after all the others, alone)
+        static const int per_cu = [] {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_closest_hit_tree, BVH_BLOCK, 0) != hipSuccess || nb < 1) nb = 8;
+            return nb < 8 ? nb : 8;
+        }();
+        const uint32_t persistent_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
+        const uint32_t want = grid.x < persistent_blocks ? grid.x : persistent_blocks;
         static const int refill_min = [] { const char* e = getenv("RRT_DEBUG_REFILL_MIN"); return e ? atoi(e) : WF_REFILL_MIN; }();  // experiments
         hipLaunchKernelGGL(wf_closest_hit_tree, dim3(want), dim3(BVH_BLOCK), 0, stream, sv, wp, parity, refill_min);
     } else if (bvh)

@@ -58,9 +58,9 @@ constexpr int WF_SHADE_SCAN_BLOCK = 512;
 constexpr int WF_HIT_BLOCK = 256;
 
 hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_t stream);
-// persistent_blocks: 256-thread blocks the device holds at once (the tree kernel's grid)
+// n_cu: compute units of the device (the tree kernel's grid is what they hold at once)
 hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity,
-                                 int persistent_blocks, hipStream_t stream);
+                                 int n_cu, hipStream_t stream);
 hipError_t wf_launch_shade(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp, int parity,
                            hipStream_t stream);
 // One kernel per trip for linear-scan scenes: closest hit + shade.  Trip t reads queue t & 1 and count[t % 3].
