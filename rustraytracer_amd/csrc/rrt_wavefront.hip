@@ -245,7 +245,11 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                 R dist[4];
                 int child[4];
                 node_children(w, q0, q1, q2, q3, dist, child);
-                node_descend(w, dist, child, push, pop);
+                // (a node pushes at most three entries: with room for three in LDS no push needs the spill test)
+                if (w.sp <= WF_STACK_LEVELS - 3)
+                    node_descend(w, dist, child, [&](int c) { s_stack[w.sp][threadIdx.x] = c; w.sp += 1; }, pop);
+                else
+                    node_descend(w, dist, child, push, pop);
                 hc.node_tests += 1;
             }
         }
