@@ -255,19 +255,21 @@ def run_rank(args):
     if hi <= lo:
         raise SystemExit("rank %d of %d has no sample index of %d spp" % (rank, world, rc.spp))
 
-    use_tree = flat.n_prims > 72
-    wavefront = args.pipeline == "wavefront" or (args.pipeline == "auto" and flat.n_prims > 150000 and args.precision == "f32")
+    reduce_ms = [0.0]  # time of the sum-reduce, summed over the timed steps (this rank's clock)
     if plumbing:
         acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32)
 
         def step():
             acc.fill_(float(hi - lo))
+            t_r = time.perf_counter()
             D.reduce_sum(acc, dst=0)
+            reduce_ms[0] += (time.perf_counter() - t_r) * 1e3
             if rank == 0 and not bool((acc == float(rc.spp)).all()):
                 raise SystemExit("the shards do not add up to %d samples per pixel" % rc.spp)
             n = (hi - lo) * rc.width * rc.height
             return {"samples": n, "rays": n, "kernel_ms": 0.0, "nonfinite": 0, "node_tests": 0, "prim_tests": 0,
-                    "bounces": [0] * 5}
+                    "bounces": [0] * 5, "accel_used": 1, "pipeline_used": 1, "tree_depth": 0, "tree_built": 0,
+                    "tree_build_ms": 0.0, "stack_overflows": 0, "exact_redos": 0}
     else:
         from rustraytracer_amd import api
 
@@ -281,15 +283,23 @@ def run_rank(args):
         acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32, device="cuda")
         img = torch.zeros((rc.height, rc.width, 3), dtype=torch.uint8, device="cuda")
 
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
         def step():
             acc.zero_()
             _, st = be.render_accumulate(scene, desc, acc)
-            if rehearsal and world > 1:
-                host = acc.cpu()
-                D.reduce_sum(host, dst=0)
-                acc.copy_(host)
-            else:
-                D.reduce_sum(acc, dst=0)
+            if world > 1:
+                # the library's kernels and the reduce run on torch's current stream: events on it bracket the reduce
+                ev0.record()
+                if rehearsal:
+                    host = acc.cpu()
+                    D.reduce_sum(host, dst=0)
+                    acc.copy_(host)
+                else:
+                    D.reduce_sum(acc, dst=0)
+                ev1.record()
+                ev1.synchronize()
+                reduce_ms[0] += ev0.elapsed_time(ev1)
             if rank == 0:
                 be.postprocess(acc, rc.spp, post, out=img)
             return st
@@ -300,9 +310,12 @@ def run_rank(args):
         if not plumbing:
             torch.cuda.synchronize()
 
+    first = None  # the statistics of the first pass: which tree it built and how long that took
     for _ in range(args.warmup):
-        step()
+        st = step()
+        first = first or st
     fence()
+    reduce_ms[0] = 0.0
     t0 = time.perf_counter()
     tot = {"samples": 0, "rays": 0, "bounces": [0] * 5, "kernel_ms": 0.0, "nonfinite": 0, "node_tests": 0,
            "prim_tests": 0}
@@ -311,8 +324,14 @@ def run_rank(args):
         for k in ("samples", "rays", "kernel_ms", "nonfinite", "node_tests", "prim_tests"):
             tot[k] += st[k]
         tot["bounces"] = [a + b for a, b in zip(tot["bounces"], st["bounces"])]
+        first = first or st
     fence()
     elapsed = time.perf_counter() - t0
+    # What ran, as the library reports it (rrt_stats), not as this script would guess it from the scene size.
+    ACCEL_NAMES = {1: "linear", 2: "lbvh", 3: "sah", 4: "sah_gpu"}
+    accel_used = ACCEL_NAMES.get(st["accel_used"], "?")
+    use_tree = accel_used != "linear"
+    wavefront = st["pipeline_used"] == 2
 
     cdev = "cpu" if rehearsal else dev
     counts = torch.tensor([tot["samples"], tot["rays"], 1.0], dtype=torch.float64, device=cdev)
@@ -322,6 +341,14 @@ def run_rank(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax[0].item())
     all_samples, all_rays, ranks_seen = float(counts[0].item()), float(counts[1].item()), int(round(float(counts[2].item())))
+    per_rank = None
+    if dist is not None:
+        # every rank's own kernel time and reduce time per step, so that a scaling curve explains itself: a slow rank,
+        # a slow reduce and launch overhead look the same in the max-over-ranks wall time
+        mine = torch.tensor([tot["kernel_ms"] / max(args.steps, 1), reduce_ms[0] / max(args.steps, 1)], dtype=torch.float64, device=cdev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = [[float(g[0].item()), float(g[1].item())] for g in gathered]
 
     if rank == 0:
         fpr = scene_flops(flat)[0]
@@ -353,7 +380,16 @@ def run_rank(args):
                             % (scene_file, width, height, xs, ys, rc.spp, lo, hi, hi - lo),
                 "pipeline": "wavefront (SoA ray/hit queues in HBM, ballot/rank compaction)" if wavefront
                 else "fused (register-resident paths, lane regeneration)",
-                "closest_hit": "tree: binned surface-area heuristic on the host threads, 4-wide quantised nodes widened and packed on the GPU" if use_tree else "linear scan (wave-uniform)",
+                "closest_hit": {"linear": "linear scan (wave-uniform)",
+                                "lbvh": "tree built on the GPU: Morton order + bottom-up clustering, 4-wide quantised nodes",
+                                "sah": "tree built by the HOST threads (binned surface-area heuristic), 4-wide quantised nodes widened and packed on the GPU",
+                                "sah_gpu": "tree built on the GPU: binned surface-area heuristic level by level, small ranges by an exact sweep, 4-wide quantised nodes",
+                                }.get(accel_used, accel_used),
+                "accel_used": accel_used,
+                "pipeline_used": "wavefront" if wavefront else "fused",
+                "tree_depth": st["tree_depth"],
+                "tree_build_ms_first_call": first["tree_build_ms"] if first and first["tree_built"] else None,
+                "stack_overflows": st["stack_overflows"],
                 "reduce": "RCCL sum-reduce of %.1f MB fp32 accumulators to rank 0" % (D.message_bytes(width, height) / 1e6)
                 if world > 1 else "none",
                 "samples_per_step": int(all_samples / args.steps),
@@ -381,6 +417,10 @@ def run_rank(args):
                 "avg_launch_ms": tot["kernel_ms"] / args.steps,
             },
         }
+        if per_rank is not None:
+            out["per_rank_kernel_ms"] = [p[0] for p in per_rank]
+            out["per_rank_reduce_ms"] = [p[1] for p in per_rank]
+            out["reduce_ms"] = max(p[1] for p in per_rank)
         if rehearsal:
             out["rehearsal"] = ("plumbing only: no GPU, nothing rendered, not a measurement" if plumbing
                                 else "all ranks on GPU 0, gloo: not a measurement")

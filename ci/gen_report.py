@@ -49,11 +49,27 @@ def convert_png_to_jpg(png_path, jpg_path):
         im.convert("RGB").save(jpg_path, "JPEG", quality=95)
 
 
+_STATS_FLAG = {}
+
+
+def takes_stats_json(executable):
+    """Whether the binary knows --stats-json: asked once through its --help.  The reference's own binary has exactly the
+    three flags -s / -r / -o (src/main.rs:25-34) and would stop at an unknown one, so it is run with those alone."""
+    key = str(executable)
+    if key not in _STATS_FLAG:
+        try:
+            r = subprocess.run([key, "--help"], capture_output=True, text=True, timeout=60)
+            _STATS_FLAG[key] = "--stats-json" in (r.stdout + r.stderr)
+        except Exception:  # noqa: BLE001
+            _STATS_FLAG[key] = False
+    return _STATS_FLAG[key]
+
+
 def run_task(executable, scene_config, render_config, out_dir, extra_args, compress=False):
     stem = Path(render_config).stem
     image, log, stats = out_dir / f"{stem}.png", out_dir / f"{stem}.log", out_dir / f"{stem}.json"
     cmd = [str(executable), "--scene-config", str(scene_config), "--render-config", str(render_config), "--output",
-           str(image), "--stats-json", str(stats), *extra_args]
+           str(image), *(["--stats-json", str(stats)] if takes_stats_json(executable) else []), *extra_args]
     t0 = time.perf_counter()
     with open(log, "w") as lf:
         proc = subprocess.run(cmd, stdout=lf, stderr=subprocess.STDOUT)

@@ -166,6 +166,14 @@ typedef struct rrt_stats {
     uint64_t nonfinite;      /* samples whose radiance was NaN/Inf (src/tracers/utils.rs:78-85 only warns) */
     double kernel_ms;        /* device time of the tracing kernels (HIP events) */
     double reserved;
+    /* What the call ran: AUTO resolved by the library, so that a caller reports the path taken, not a guess. */
+    uint32_t accel_used;     /* rrt_accel: LINEAR, LBVH, SAH or SAH_GPU, never AUTO */
+    uint32_t pipeline_used;  /* rrt_pipeline: FUSED or WAVEFRONT, never AUTO */
+    uint32_t tree_depth;     /* levels of wide nodes of the tree that was walked (0: no tree) */
+    uint32_t tree_built;     /* 1 when this call built the tree (the first call that needs it), else 0 */
+    double tree_build_ms;    /* host wall time of that build, upload of its inputs included (0 when tree_built = 0) */
+    uint64_t stack_overflows; /* traversal-stack entries dropped (always 0: the build refuses trees the stack cannot hold) */
+    uint64_t exact_redos;    /* closest-hit queries repeated in f64 (RRT_RENDER_EXACT_HITS), see rrt_render_flags */
 } rrt_stats;
 
 typedef struct rrt_scene rrt_scene;
@@ -204,13 +212,15 @@ int rrt_trace_primary(rrt_backend* backend, const rrt_scene* scene, uint32_t pre
                       size_t n, const double* u, const double* v,
                       int32_t* object_id, int32_t* prim_id, double* t);
 
-/* rrt_intersect without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
- * allocate device memory at the time of the call (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  rrt_intersect allocates five staging buffers per call; this variant stages the rays and the
- * results in a fixed array that lives in the library's device image (4 MiB per GPU the library runs on, held until
- * the process ends), so it takes at most RRT_INTERSECT_STATIC_MAX_RAYS rays per call and fails with RRT_ERR_INVALID
- * beyond that.  The scene must already be resident on the backend's device (and its tree built, if `accel` asks for
- * one): one earlier rrt_intersect call with the same scene and accel does both; otherwise RRT_ERR_INVALID.
+/* rrt_intersect without any device allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that must
+ * not allocate device memory at the time of the call (tight serving loops, harnesses that forbid hipMalloc, a process
+ * whose memory is spoken for).  rrt_intersect allocates five staging buffers per call; this variant stages the rays
+ * and the results in a fixed array that lives in the library's device image (4 MiB per GPU the library runs on, held
+ * until the process ends), so it takes at most RRT_INTERSECT_STATIC_MAX_RAYS rays per call and fails with
+ * RRT_ERR_INVALID beyond that.  It still copies from and to the caller's HOST arrays and waits for the stream before it
+ * returns, so it is NOT a call that can be recorded into a HIP graph.  The scene must already be resident on the
+ * backend's device (and its tree built, if `accel` asks for one): one earlier rrt_intersect call with the same scene and
+ * accel does both; otherwise RRT_ERR_INVALID.
  * Same arguments, results and kernels as rrt_intersect.  Every call on one GPU uses that GPU's one array: calls that
  * overlap on a GPU (two host threads, two backends on the same device) race and must be serialised by the caller. */
 #define RRT_INTERSECT_STATIC_MAX_RAYS 65536

@@ -90,6 +90,13 @@ class Stats(C.Structure):
         ("nonfinite", C.c_uint64),
         ("kernel_ms", C.c_double),
         ("reserved", C.c_double),
+        ("accel_used", C.c_uint32),
+        ("pipeline_used", C.c_uint32),
+        ("tree_depth", C.c_uint32),
+        ("tree_built", C.c_uint32),
+        ("tree_build_ms", C.c_double),
+        ("stack_overflows", C.c_uint64),
+        ("exact_redos", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -102,6 +109,13 @@ class Stats(C.Structure):
             "nonfinite": int(self.nonfinite),
             "kernel_ms": float(self.kernel_ms),
             "reserved": float(self.reserved),
+            "accel_used": int(self.accel_used),
+            "pipeline_used": int(self.pipeline_used),
+            "tree_depth": int(self.tree_depth),
+            "tree_built": int(self.tree_built),
+            "tree_build_ms": float(self.tree_build_ms),
+            "stack_overflows": int(self.stack_overflows),
+            "exact_redos": int(self.exact_redos),
         }
 
 

@@ -4,6 +4,7 @@
 // device or fails with an error code.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -13,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "../../include/rrt.h"
@@ -190,9 +192,13 @@ struct DeviceScene {
     rrt::LightView<float> l32{};
     rrt::LightView<double> l64{};
     // One tree per builder (rrt_accel): [0] the cluster tree built on the GPU, [1] the surface-area tree built on the
-    // host.  The kernels read whichever select_tree() put into the views last.
+    // host.  v32 / v64 themselves never point at a tree: every call makes its own copy of the view and puts the tree
+    // it asked for into that copy (with_tree), so two host threads that use one scene with different builders never
+    // see each other's choice.
     struct Tree {
         bool built = false;
+        int depth = 0;           // levels of wide nodes
+        double build_ms = 0.0;   // host wall time of the build
         const rrt::WideNode* nodes = nullptr;
         const rrt::LeafRec<float>* leaves32 = nullptr;
         const rrt::LeafRec<double>* leaves64 = nullptr;
@@ -461,26 +467,36 @@ float round_up(double x) {
     return (double)f < x ? std::nextafterf(f, INFINITY) : f;
 }
 
-// Points the scene views at one of the scene's trees.
-void select_tree(DeviceScene* ds, int kind) {
+// A copy of a scene view that points at one of the scene's trees (kind < 0: none, the linear scan).
+rrt::SceneView<float> with_tree(const rrt_backend* be, const DeviceScene* ds, const rrt::SceneView<float>& base, int kind) {
+    rrt::SceneView<float> v = base;
+    v.stack_overflow = be->d_counters + rrt::COUNTER_STACK_OVERFLOW;
+    if (kind < 0) return v;
     const DeviceScene::Tree& t = ds->tree[kind];
-    ds->v32.nodes = ds->v64.nodes = t.nodes;
-    ds->v32.leaves = t.leaves32;
-    ds->v64.leaves = t.leaves64;
-    ds->v32.bvh_prim = ds->v64.bvh_prim = t.bvh_prim;
-    ds->v32.linear_prim = ds->v64.linear_prim = t.linear_prim;
-    ds->v32.n_bvh_prims = ds->v64.n_bvh_prims = t.n_bvh_prims;
-    ds->v32.n_linear_prims = ds->v64.n_linear_prims = t.n_linear_prims;
+    v.nodes = t.nodes; v.leaves = t.leaves32; v.bvh_prim = t.bvh_prim; v.linear_prim = t.linear_prim;
+    v.n_bvh_prims = t.n_bvh_prims; v.n_linear_prims = t.n_linear_prims;
+    return v;
+}
+rrt::SceneView<double> with_tree(const rrt_backend* be, const DeviceScene* ds, const rrt::SceneView<double>& base, int kind) {
+    rrt::SceneView<double> v = base;
+    v.stack_overflow = be->d_counters + rrt::COUNTER_STACK_OVERFLOW;
+    if (kind < 0) return v;
+    const DeviceScene::Tree& t = ds->tree[kind];
+    v.nodes = t.nodes; v.leaves = t.leaves64; v.bvh_prim = t.bvh_prim; v.linear_prim = t.linear_prim;
+    v.n_bvh_prims = t.n_bvh_prims; v.n_linear_prims = t.n_linear_prims;
+    return v;
 }
 
-// Builds a tree of a device scene on first use (shared by the f32 and f64 views: boxes are f32) and selects it.
+// Builds a tree of a device scene on first use (shared by the f32 and f64 views: boxes are f32).
 // kind 0: clustering along the Morton order, built on the GPU (rrt_lbvh.hip, rrt_ploc.hip); kind 1: binned surface-area
 // heuristic, built by the host's threads (rrt_sah.hpp).  Both end in the same 4-wide quantised nodes and leaf records.
+// A traversal holds at most three stack entries per level of wide nodes, and the kernels' stacks hold
+// kTreeStackEntries: a tree deeper than that (the cost function can peel primitives off one by one on adversarial
+// input; the clustering makes one level per round) is rebuilt with median cuts, which bound the depth by log2 n.
+const int kTreeStackEntries = rrt::BVH_STACK_ENTRIES;
 int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) {
-    if (ds->tree[kind].built) {
-        select_tree(ds, kind);
-        return RRT_OK;
-    }
+    if (ds->tree[kind].built) return RRT_OK;
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<int32_t> bounded, unbounded;  // scan-order indices
     std::vector<float> lo, hi;
     double slo[3] = {INFINITY, INFINITY, INFINITY}, shi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -552,6 +568,7 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
     if ((rc = upload(ds, unbounded, &d_lin, be->stream)) != RRT_OK) return rc;
     const int32_t* d_slot = nullptr;
     const rrt::WideNode* d_nodes = nullptr;
+    int depth = 0;
     if (n == 1) {
         if ((rc = upload(ds, bounded, &d_slot, be->stream)) != RRT_OK) return rc;
     } else if (n >= 2) {
@@ -561,11 +578,27 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
         HIP_TRY(hipMalloc(&slots, sizeof(int32_t) * (size_t)n));
         ds->allocs.push_back(slots);
         std::vector<int32_t> map;  // sorted slot -> index among the bounded primitives
+        // The host builder: threads and vectors; nothing may unwind through the C ABI.
+        auto host_tree = [&](bool median) -> int {
+            try {
+                std::vector<rrt::BvhNode> binary;
+                int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+                try {
+                    rrt::SahBuilder(lo.data(), hi.data(), n, kBvhLeafMax).build(binary, map, threads, median);
+                } catch (const std::system_error&) {  // no more threads to be had (a container's pid limit): alone, then
+                    rrt::SahBuilder(lo.data(), hi.data(), n, kBvhLeafMax).build(binary, map, 1, median);
+                }
+                HIP_TRY(rrt::bvh_widen_host_tree(binary.data(), (int)binary.size(), (rrt::WideNode*)nodes, be->stream, &depth));
+            } catch (const std::bad_alloc&) {
+                return fail(RRT_ERR_NOMEM, "out of host memory while building the tree of %d primitives", n);
+            } catch (const std::exception& e) {
+                return fail(RRT_ERR_HIP, "the tree build failed: %s", e.what());
+            }
+            return RRT_OK;
+        };
+        bool on_host = kind == 1;
         if (kind == 1) {
-            std::vector<rrt::BvhNode> binary;
-            const int threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-            rrt::SahBuilder(lo.data(), hi.data(), n, kBvhLeafMax).build(binary, map, threads);
-            HIP_TRY(rrt::bvh_widen_host_tree(binary.data(), (int)binary.size(), (rrt::WideNode*)nodes, be->stream));
+            if ((rc = host_tree(false)) != RRT_OK) return rc;
         } else {
             DevBuf dlo, dhi;
             HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));
@@ -574,7 +607,15 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
             HIP_TRY(hipMemcpyAsync(dhi.p, hi.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
             float flo[3], fhi[3];
             for (int k = 0; k < 3; ++k) { flo[k] = round_down(slo[k]); fhi[k] = round_up(shi[k]); }
-            HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, (rrt::WideNode*)nodes, (int*)slots, be->stream));
+            HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, (rrt::WideNode*)nodes, (int*)slots, be->stream, &depth));
+        }
+        if (3 * depth > kTreeStackEntries) {  // too deep for the traversal stacks: median cuts instead
+            if ((rc = host_tree(true)) != RRT_OK) return rc;
+            on_host = true;
+            if (3 * depth > kTreeStackEntries)
+                return fail(RRT_ERR_UNSUPPORTED, "the tree of %d primitives is %d levels deep; the traversal stacks hold %d", n, depth, kTreeStackEntries / 3);
+        }
+        if (!on_host) {
             map.resize((size_t)n);
             HIP_TRY(hipMemcpy(map.data(), slots, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
         }
@@ -605,8 +646,9 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
     tree.linear_prim = d_lin;
     tree.n_bvh_prims = n;
     tree.n_linear_prims = (int32_t)unbounded.size();
+    tree.depth = depth;
+    tree.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     tree.built = true;
-    select_tree(ds, kind);
     return RRT_OK;
 }
 
@@ -618,10 +660,11 @@ int tree_kind(const rrt_scene* sc, uint32_t accel) {
 }
 
 // AUTO: the surface-area tree for scenes too large for the wave-uniform scan; LBVH, SAH: that tree; LINEAR: none.
-int resolve_accel(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, uint32_t accel, bool* use_bvh) {
-    const int kind = tree_kind(sc, accel);
-    *use_bvh = kind >= 0;
-    return *use_bvh ? ensure_bvh(be, sc, ds, kind) : RRT_OK;
+// *kind = the tree the call walks (-1: none); *built_now = whether this call built it.
+int resolve_accel(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, uint32_t accel, int* kind, bool* built_now = nullptr) {
+    *kind = tree_kind(sc, accel);
+    if (built_now) *built_now = *kind >= 0 && !ds->tree[*kind].built;
+    return *kind >= 0 ? ensure_bvh(be, sc, ds, *kind) : RRT_OK;
 }
 
 // How a caller's buffer is used.  Kernels write in place only into plain device memory of the backend's own GPU:
@@ -665,8 +708,9 @@ int closest_hit_call(rrt_backend* be, const rrt_scene* scene, uint32_t precision
     }
     DeviceScene* ds = nullptr;
     if ((rc = device_scene(be, scene, &ds)) != RRT_OK) return rc;
-    bool use_bvh = false;
-    if ((rc = resolve_accel(be, scene, ds, accel, &use_bvh)) != RRT_OK) return rc;
+    int kind = -1;
+    if ((rc = resolve_accel(be, scene, ds, accel, &kind)) != RRT_OK) return rc;
+    const bool use_bvh = kind >= 0;
     const size_t per = primary ? 1 : 3;
     DevBuf da, db, doid, dpid, dt;
     HIP_TRY(da.alloc(n * per * sizeof(double)));
@@ -677,10 +721,10 @@ int closest_hit_call(rrt_backend* be, const rrt_scene* scene, uint32_t precision
     HIP_TRY(hipMemcpyAsync(da.p, a, n * per * sizeof(double), hipMemcpyHostToDevice, be->stream));
     HIP_TRY(hipMemcpyAsync(db.p, b, n * per * sizeof(double), hipMemcpyHostToDevice, be->stream));
     if (precision == RRT_PRECISION_F64)
-        HIP_TRY(rrt::launch_intersect(ds->v64, use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
+        HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v64, kind), use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
                                       (int32_t*)doid.p, (int32_t*)dpid.p, (double*)dt.p, be->stream));
     else
-        HIP_TRY(rrt::launch_intersect(ds->v32, use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
+        HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v32, kind), use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
                                       (int32_t*)doid.p, (int32_t*)dpid.p, (double*)dt.p, be->stream));
     HIP_TRY(hipMemcpyAsync(object_id, doid.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipMemcpyAsync(prim_id, dpid.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
@@ -912,9 +956,12 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
     }
     std::vector<unsigned long long> rows(rows_bytes / sizeof(unsigned long long));
     HIP_TRY(hipMemcpyAsync(rows.data(), wp.block_counters, rows_bytes, hipMemcpyDeviceToHost, be->stream));
+    unsigned long long dropped = 0;  // (the tree walks report through the view's own counter word, not through the rows)
+    HIP_TRY(hipMemcpyAsync(&dropped, be->d_counters + rrt::COUNTER_STACK_OVERFLOW, sizeof(dropped), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipStreamSynchronize(be->stream));
     for (int k = 0; k < rrt::COUNTER_COUNT; ++k) counters[k] = 0;
     for (size_t i = 0; i < rows.size(); ++i) counters[i % rrt::COUNTER_COUNT] += rows[i];
+    counters[rrt::COUNTER_STACK_OVERFLOW] += dropped;
     counters[rrt::COUNTER_RAYS] = ctl.rays;
     if (!use_bvh) counters[rrt::COUNTER_PRIM_TESTS] = ctl.rays * (unsigned long long)sv.n_prims;
     return RRT_OK;
@@ -1076,7 +1123,6 @@ int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t preci
     DeviceScene* ds = it->second;
     const int kind = tree_kind(scene, accel);
     const bool use_bvh = kind >= 0;
-    if (use_bvh && ds->tree[kind].built) select_tree(ds, kind);  // pointers only
     if (use_bvh && !ds->tree[kind].built)
         return fail(RRT_ERR_INVALID, "rrt_intersect_static: the scene's tree is not built on device %d yet; make one "
                                      "rrt_intersect call with the same scene and accel first", be->device);
@@ -1087,9 +1133,9 @@ int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t preci
     HIP_TRY(hipMemcpyAsync(sp->origins, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice, be->stream));
     HIP_TRY(hipMemcpyAsync(sp->dirs, dirs, n * 3 * sizeof(double), hipMemcpyHostToDevice, be->stream));
     if (precision == RRT_PRECISION_F64)
-        HIP_TRY(rrt::launch_intersect(ds->v64, use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
+        HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v64, kind), use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
     else
-        HIP_TRY(rrt::launch_intersect(ds->v32, use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
+        HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v32, kind), use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
     HIP_TRY(hipMemcpyAsync(object_id, sp->object_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipMemcpyAsync(prim_id, sp->prim_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipMemcpyAsync(t, sp->t, n * sizeof(double), hipMemcpyDeviceToHost, be->stream));
@@ -1108,8 +1154,10 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         return fail(RRT_ERR_UNSUPPORTED, "the wavefront pipeline keeps its queues in f32; use the fused pipeline for f64");
     DeviceScene* ds = nullptr;
     if ((rc = device_scene(be, scene, &ds)) != RRT_OK) return rc;
-    bool use_bvh = false;
-    if ((rc = resolve_accel(be, scene, ds, desc->accel, &use_bvh)) != RRT_OK) return rc;
+    int kind = -1;
+    bool built_now = false;
+    if ((rc = resolve_accel(be, scene, ds, desc->accel, &kind, &built_now)) != RRT_OK) return rc;
+    const bool use_bvh = kind >= 0;
     // AUTO: tree traversal wants many waves in flight, which the register-lean closest-hit kernel of
     // the wavefront pipeline has; a scan over a few primitives is fastest with the path in registers
     const bool nee = (desc->flags & RRT_RENDER_NEE) != 0;
@@ -1147,12 +1195,12 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     unsigned long long counter_rows[rrt::COUNTER_ROWS * rrt::COUNTER_COUNT];
     HIP_TRY(hipEventRecord(be->ev0, be->stream));
     if (desc->max_depth > 0 && wavefront) {
-        if ((rc = render_wavefront(be, ds->v32, use_bvh, rp, counters)) != RRT_OK) return rc;
+        if ((rc = render_wavefront(be, with_tree(be, ds, ds->v32, kind), use_bvh, rp, counters)) != RRT_OK) return rc;
     } else if (desc->max_depth > 0) {
         if (desc->precision == RRT_PRECISION_F64)
-            HIP_TRY(rrt::launch_render_fused(ds->v64, ds->l64, use_bvh, rp, n_blocks, be->stream));
+            HIP_TRY(rrt::launch_render_fused(with_tree(be, ds, ds->v64, kind), ds->l64, use_bvh, rp, n_blocks, be->stream));
         else
-            HIP_TRY(rrt::launch_render_fused(ds->v32, ds->l32, use_bvh, rp, n_blocks, be->stream));
+            HIP_TRY(rrt::launch_render_fused(with_tree(be, ds, ds->v32, kind), ds->l32, use_bvh, rp, n_blocks, be->stream));
     }
     HIP_TRY(hipEventRecord(be->ev1, be->stream));
 
@@ -1184,6 +1232,12 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         stats->node_tests = counters[rrt::COUNTER_NODE_TESTS];
         for (int k = 0; k < 5; ++k) stats->bounces[k] = counters[rrt::COUNTER_BOUNCE0 + k];
         stats->nonfinite = counters[rrt::COUNTER_NONFINITE];
+        stats->accel_used = kind < 0 ? RRT_ACCEL_LINEAR : (kind == 0 ? RRT_ACCEL_LBVH : RRT_ACCEL_SAH);
+        stats->pipeline_used = wavefront ? RRT_PIPELINE_WAVEFRONT : RRT_PIPELINE_FUSED;
+        stats->tree_depth = kind >= 0 ? (uint32_t)ds->tree[kind].depth : 0u;
+        stats->tree_built = built_now ? 1u : 0u;
+        stats->tree_build_ms = built_now ? ds->tree[kind].build_ms : 0.0;
+        stats->stack_overflows = counters[rrt::COUNTER_STACK_OVERFLOW];
     }
     return RRT_OK;
 }

@@ -44,13 +44,13 @@ RRT_DEV int hit_winner(const HitAcc<R>& h) {
 // Traversal stack of node links: the first BVH_LDS_LEVELS entries of every lane live in LDS
 // ([level][thread], so the 64 lanes of a wave hit 64 different banks), deeper entries in a private
 // spill array that a well-formed tree rarely reaches (a divergent private-memory access costs as
-// much as a divergent global one).  A 4-wide node pushes at most three entries per level, and the
-// binary radix tree under it (63-bit codes + 32-bit position tie-break) is at most 95 levels deep,
-// i.e. 48 wide levels.  Entries carry no distance: a stale entry costs one node fetch whose children
+// much as a divergent global one).  A 4-wide node pushes at most three entries per level it descends; neither
+// builder bounds the depth of its tree by construction, so the host measures it after every build and admits only
+// trees of at most BVH_STACK_ENTRIES / 3 levels (rrt_types.hpp).  A push onto a full stack -- which such a tree
+// cannot cause -- drops the link and counts it (SceneView::stack_overflow) rather than writing out of bounds.
+// Entries carry no distance: a stale entry costs one node fetch whose children
 // all fail, which happens for ~5 % of the nodes, and half the bytes per entry keep twice as many
 // levels in LDS at full occupancy.
-constexpr int BVH_LDS_LEVELS = 12;
-constexpr int BVH_SPILL_LEVELS = 3 * 48 - BVH_LDS_LEVELS;
 constexpr int BVH_BLOCK = 256;  // every kernel that traverses the tree runs 256-thread blocks
 constexpr int BVH_DONE = BVH_NO_CHILD;
 
@@ -123,9 +123,15 @@ RRT_DEV void walk_start(TreeWalk<R>& w, V3<R> o, V3<R> d) {
 }
 
 template <typename R>
-RRT_DEV void walk_push(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, int node) {
-    if (w.sp < BVH_LDS_LEVELS) lds.node[w.sp][threadIdx.x] = node;
-    else if (w.sp < BVH_LDS_LEVELS + BVH_SPILL_LEVELS) spill[w.sp - BVH_LDS_LEVELS] = node;
+RRT_DEV void walk_push(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, int node, unsigned long long* overflow) {
+    if (w.sp < BVH_LDS_LEVELS) {
+        lds.node[w.sp][threadIdx.x] = node;
+    } else if (w.sp < BVH_STACK_ENTRIES) {
+        spill[w.sp - BVH_LDS_LEVELS] = node;
+    } else {
+        atomicAdd(overflow, 1ull);
+        return;
+    }
     w.sp += 1;
 }
 
@@ -210,11 +216,12 @@ RRT_DEV void node_descend(TreeWalk<R>& w, R (&dist)[4], int (&child)[4], Push pu
 }
 
 template <typename R>
-RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, uint4 q0, uint4 q1, uint4 q2, uint4 q3) {
+RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, uint4 q0, uint4 q1, uint4 q2, uint4 q3,
+                       unsigned long long* overflow) {
     R dist[4];
     int child[4];
     node_children(w, q0, q1, q2, q3, dist, child);
-    node_descend(w, dist, child, [&](int c) { walk_push(w, lds, spill, c); }, [&]() { walk_pop(w, lds, spill); });
+    node_descend(w, dist, child, [&](int c) { walk_push(w, lds, spill, c, overflow); }, [&]() { walk_pop(w, lds, spill); });
 }
 
 // One leaf primitive, given as the four 16-byte words of its LeafRec<float> record, against the ray.
@@ -305,7 +312,7 @@ RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, 
             if (w.node >= 0) {
                 uint4 q0, q1, q2, q3;
                 tree_node_words(sv, w.node, top_n, q0, q1, q2, q3);
-                walk_node(w, s_stack, spill, q0, q1, q2, q3);
+                walk_node(w, s_stack, spill, q0, q1, q2, q3, sv.stack_overflow);
                 hc.node_tests += 1;
             }
             if (w.node < 0 && w.node != BVH_DONE) {  // (in the same trip as the node step that led here)

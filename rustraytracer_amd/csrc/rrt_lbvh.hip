@@ -166,8 +166,9 @@ pack_leaves_kernel(const PrimRec<R>* __restrict__ prims, const int* __restrict__
     out[s] = r;
 }
 
-// d_wide = the wide nodes of the m binary nodes at d_nodes (marked, node 0 the root), packed.  Synchronises the stream.
-static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide, hipStream_t stream) {
+// d_wide = the wide nodes of the m binary nodes at d_nodes (marked, node 0 the root), packed; *depth = the levels of
+// wide nodes (what bounds a traversal stack: a walk holds at most three entries per level).  Synchronises the stream.
+static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide, hipStream_t stream, int* depth) {
     const int n = m + 1;  // the kernels take the primitive count of a full binary tree
     hipError_t e;
     WideNode* wide_tmp = nullptr;
@@ -194,6 +195,7 @@ static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide
         LBVH_TRY(hipGetLastError());
         LBVH_TRY(hipMemcpyAsync(&again, marked, sizeof(int), hipMemcpyDeviceToHost, stream));
         LBVH_TRY(hipStreamSynchronize(stream));
+        *depth = round + 1;
         if (!again) break;
         if (round > m) LBVH_TRY(hipErrorUnknown);
     }
@@ -213,7 +215,7 @@ static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide
 }
 
 hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float scene_lo[3], const float scene_hi[3],
-                      WideNode* d_wide, int* d_prim_of_slot, hipStream_t stream) {
+                      WideNode* d_wide, int* d_prim_of_slot, hipStream_t stream, int* depth) {
     if (n < 2 || n > BVH_MAX_PRIMS) return hipErrorInvalidValue;
     hipError_t e;
     BvhNode* d_nodes = nullptr;
@@ -242,19 +244,19 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
     LBVH_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, index_in, index_out, (size_t)n, 0, 63,
                                        stream));
     LBVH_TRY(ploc_build(d_lo, d_hi, d_prim_of_slot, n, d_nodes, stream));
-    LBVH_TRY(widen_and_pack(d_nodes, n - 1, d_wide, stream));
+    LBVH_TRY(widen_and_pack(d_nodes, n - 1, d_wide, stream, depth));
 #undef LBVH_TRY
     cleanup();
     return hipSuccess;
 }
 
 // The wide nodes of a binary tree built and marked on the host (rrt_sah.hpp): m binary nodes, node 0 the root.
-hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, WideNode* d_wide, hipStream_t stream) {
+hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, WideNode* d_wide, hipStream_t stream, int* depth) {
     if (m < 1) return hipErrorInvalidValue;
     BvhNode* d_nodes = nullptr;
     hipError_t e = hipMalloc(&d_nodes, sizeof(BvhNode) * (size_t)m);
     if (e == hipSuccess) e = hipMemcpyAsync(d_nodes, h_nodes, sizeof(BvhNode) * (size_t)m, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = widen_and_pack(d_nodes, m, d_wide, stream);
+    if (e == hipSuccess) e = widen_and_pack(d_nodes, m, d_wide, stream, depth);
     (void)hipFree(d_nodes);
     return e;
 }

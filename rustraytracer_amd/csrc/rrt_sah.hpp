@@ -87,7 +87,11 @@ public:
     // The top of the tree is split on the calling thread down to ranges of at most `grain` primitives; those
     // subtrees are independent jobs for `threads` threads.  Ranges, cuts and the order of the records depend
     // on the input alone, not on the number of threads.
-    void build(std::vector<BvhNode>& nodes, std::vector<int32_t>& prim_of_slot, int threads) {
+    // median = true: every range is cut in the middle of its order along its longest coordinate instead (no cost
+    // function): a tree of depth ceil(log2 n), for inputs on which the cost function peels primitives off one by one
+    // and the tree would be deeper than a traversal stack holds.
+    void build(std::vector<BvhNode>& nodes, std::vector<int32_t>& prim_of_slot, int threads, bool median = false) {
+        median_ = median;
         prim_of_slot.resize((size_t)n_);
         for (int i = 0; i < n_; ++i) prim_of_slot[(size_t)i] = i;
         idx_ = prim_of_slot.data();
@@ -204,6 +208,7 @@ private:
     std::vector<int32_t> temp_;  // scratch of the top-of-tree partition
     float coord(size_t p, int a) const { return a < 3 ? 0.5f * (lo_[3 * p + a] + hi_[3 * p + a]) : size_[p]; }
     int top_threads_ = 1;
+    bool median_ = false;
     struct Extent {
         float lo[AXES], hi[AXES];
         void clear() { for (int a = 0; a < AXES; ++a) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; } }
@@ -307,6 +312,21 @@ private:
 
     // Where to cut [first, first + count): returns the size of the left part (1 .. count - 1) and the boxes of the parts.
     int partition(int first, int count, SahBox& bl, SahBox& br) {
+        if (median_) {
+            Extent e;
+            e.clear();
+            extent(first, count, e);
+            int a = 0;
+            for (int k = 1; k < 3; ++k)
+                if (e.hi[k] - e.lo[k] > e.hi[a] - e.lo[a]) a = k;
+            std::nth_element(idx_ + first, idx_ + first + count / 2, idx_ + first + count, [&](int32_t x, int32_t y) {
+                const float cx = coord((size_t)x, a), cy = coord((size_t)y, a);
+                return cx < cy || (cx == cy && x < y);
+            });
+            bl = bounds_of(first, count / 2);
+            br = bounds_of(first + count / 2, count - count / 2);
+            return count / 2;
+        }
         if (count <= SWEEP_MAX) return partition_sweep(first, count, bl, br);
         Extent ext;
         ext.clear();

@@ -125,7 +125,8 @@ RRT_DEV int process_hit(const RenderParams& rp, Path<R>& p, const ShadeRec<R>& s
 //   Lambertian      (|c| albedo/pi) / (c/pi)                 = albedo
 //   PhongSpecular   |d.n| spec (s+2)/(2pi) c^s / (c^s (s+1)/(2pi)) = spec |d.n| (s+2)/(s+1)
 //   IdealReflector  c (1/c) / 1                              = 1   (0 if d.n <= 1e-6)
-//   IdealDielectric reflect: c (F/c) / F = 1; refract: c ((1-F)/(c eta^2)) / (1-F) = 1/eta^2
+//   IdealDielectric reflect: c (F/c) / F = 1; refract: c ((1-F)/(c eta^2)) / (1-F) = 1/eta^2, except where the refracted
+//                   direction also passes bxdf's test for the reflected one, which comes first: c (F/c) / (1-F)
 //                   (0 if |d.n| < 1e-6)
 // A path whose throughput became exactly zero is dropped: it can only add zero.
 // draw_1d() supplies the dielectric's reflect-or-refract draw (the path's sampler in the renderers,
@@ -198,6 +199,12 @@ RRT_DEV bool scatter_with(Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u
             dir = mk<R>(eta * p.d.x + k * on.x, eta * p.d.y + k * on.y, eta * p.d.z + k * on.z);
             pdf = R(1) - F;
             w = inside ? m.b : m.g;  // 1 / eta^2
+            // Material::bxdf asks "is it the reflected direction?" FIRST (src/material.rs:269-273), so a refracted ray
+            // within 1e-3 of the reflected one -- a grazing ray through a boundary with eta close to 1 -- is weighted
+            // with the reflect formula F / cos although it was sampled with probability 1 - F: factor F / (1 - F).
+            // |reflect - refract|^2 with reflect = d + 2 c on, refract = eta d + (eta c - cos_t) on, d . on = -c:
+            const R a = R(1) - eta, q = cos_theta * (R(2) - eta) + cos_t2;
+            if (a * a + q * (q - R(2) * a * cos_theta) < Num<R>::eps()) w = F * Num<R>::rcp(pdf);
         }
         if (pdf <= Num<R>::eps()) return false;
         if (Num<R>::abs(dot(dir, n)) < Num<R>::eps()) return false;

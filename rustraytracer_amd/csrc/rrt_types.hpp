@@ -113,6 +113,13 @@ struct alignas(sizeof(R) == 4 ? 64 : 128) LeafRec {
 // is set by how few bytes a step needs, and 4-wide nodes halve the dependent fetches per ray.
 // Indexed like the binary nodes; node 0 is the root.
 constexpr int BVH_NO_CHILD = (int)0x80000000;
+// Traversal stacks (rrt_bvh.hpp) hold BVH_STACK_ENTRIES node links per lane: the first BVH_LDS_LEVELS in LDS, the rest
+// in a private array.  A walk pushes at most three links per level of 4-wide nodes it descends, so a tree of up to
+// BVH_STACK_ENTRIES / 3 levels can never overflow a stack; the host measures the depth of every tree it builds and
+// rebuilds a deeper one with median cuts (rrt_api.cpp, ensure_bvh).
+constexpr int BVH_LDS_LEVELS = 12;
+constexpr int BVH_STACK_ENTRIES = 144;
+constexpr int BVH_SPILL_LEVELS = BVH_STACK_ENTRIES - BVH_LDS_LEVELS;
 struct alignas(64) WideNode {
     float org[3];
     uint8_t e[3];
@@ -163,6 +170,9 @@ struct SceneView {
     const int32_t* linear_prim; // primitives kept out of the tree (unbounded planes, bent quads), scan order
     int32_t n_bvh_prims;
     int32_t n_linear_prims;
+    // where a walk reports a link it had to drop because its stack was full (never happens with a tree the host admitted;
+    // counted instead of silently losing a subtree)
+    unsigned long long* stack_overflow;
 };
 
 // The area lights of a scene: a kernel argument of its own, read by the next-event-estimation kernels only (as fields
@@ -213,6 +223,8 @@ enum : int {
     COUNTER_BOUNCE0 = 3,   // +material type, 5 entries
     COUNTER_NONFINITE = 8,
     COUNTER_SAMPLES = 9,
+    COUNTER_STACK_OVERFLOW = 10,  // traversal-stack entries dropped (a tree deeper than the build admits)
+    COUNTER_EXACT_REDOS = 11,     // closest-hit queries repeated in f64
     COUNTER_COUNT = 16
 };
 // The fused kernel's waves add their event counts to one of COUNTER_ROWS copies of the counter block (summed on the

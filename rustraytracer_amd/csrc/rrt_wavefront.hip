@@ -154,7 +154,7 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
     uint32_t off = 0;
     const WfQueue& q = wp.q[parity];
 
-    int spill[3 * 48 - WF_STACK_LEVELS];  // (see TreeStackSpill)
+    int spill[BVH_STACK_ENTRIES - WF_STACK_LEVELS];  // (see TreeStackSpill)
     TreeWalk<R> w;
     w.o = mk<R>(0, 0, 0);
     w.d = w.inv_d = mk<R>(0, 0, 1);
@@ -165,8 +165,14 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
     uint32_t mine = 0;
     bool have = false;
     auto push = [&](int node) {
-        if (w.sp < WF_STACK_LEVELS) s_stack[w.sp][threadIdx.x] = node;
-        else spill[w.sp - WF_STACK_LEVELS] = node;
+        if (w.sp < WF_STACK_LEVELS) {
+            s_stack[w.sp][threadIdx.x] = node;
+        } else if (w.sp < BVH_STACK_ENTRIES) {
+            spill[w.sp - WF_STACK_LEVELS] = node;
+        } else {  // cannot happen with a tree the host admitted (rrt_types.hpp): counted, never written out of bounds
+            atomicAdd(sv.stack_overflow, 1ull);
+            return;
+        }
         w.sp += 1;
     };
     auto pop = [&]() {

@@ -30,6 +30,10 @@ def test_self_launch_two_ranks_strong():
     assert d["config"]["samples_per_step"] == 500 * 500 * 64
     assert "[0, 32)" in d["config"]["workload"] and "64 spp in total" in d["config"]["workload"]
     assert "rehearsal" in d and "cpu_baseline" not in d
+    # the line explains itself: every rank's kernel time and reduce time per step, and the path the library reports
+    assert len(d["per_rank_kernel_ms"]) == 2 and len(d["per_rank_reduce_ms"]) == 2
+    assert d["reduce_ms"] == max(d["per_rank_reduce_ms"]) and d["reduce_ms"] > 0
+    assert d["config"]["accel_used"] == "linear" and d["config"]["pipeline_used"] == "fused"
 
 
 def test_self_launch_weak_scaling_three_ranks():

@@ -105,5 +105,5 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_abi.SceneDesc) == 96 + 8 + 16
     assert C.sizeof(_abi.RenderDesc) == 72
     assert C.sizeof(_abi.PostDesc) == 40
-    assert C.sizeof(_abi.Stats) == 8 * 4 + 40 + 8 + 16
+    assert C.sizeof(_abi.Stats) == 8 * 4 + 40 + 8 + 16 + 16 + 8 + 16
     assert _abi.PRIM_DTYPE.itemsize == 112 and _abi.MATERIAL_DTYPE.itemsize == 40

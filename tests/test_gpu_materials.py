@@ -177,6 +177,47 @@ def test_ideal_dielectric(gpu, O, prec_name, ior):  # src/material.rs:193-284, s
         assert np.all(np.einsum("ij,ij->i", d_out[sel], np.where(inside[sel, None], -n[sel], n[sel])) >= 0)
 
 
+@pytest.mark.parametrize("ior", [1.0, 1.00000005])
+def test_dielectric_grazing_ray_takes_the_reflect_formula(gpu, O, ior):
+    """Material::bxdf tests `|reflect - out|^2 < 1e-6` BEFORE the refracted direction (src/material.rs:269-273).  Through a
+    boundary whose two indices (nearly) agree, a refracted ray that grazes the surface (|d . n| < 5e-4) also passes that
+    first test, so the reference weights it with F / cos_t although it was sampled with probability 1 - F: the path's
+    throughput gets F / (1 - F), not 1 / eta^2.  The f64 kernels must follow, ray by ray; steeper rays are unaffected."""
+    api, be = gpu
+    rng = np.random.default_rng(77)
+    n = _unit(rng.normal(size=(N, 3)))
+    tangent = _unit(np.cross(n, rng.normal(size=(N, 3))))
+    c = np.where(np.arange(N) % 2 == 0, 10 ** rng.uniform(-5, np.log10(4e-4), N), 10 ** rng.uniform(np.log10(2e-3), -0.3, N))
+    c = c * rng.choice([-1.0, 1.0], N)                      # from outside and from inside
+    d = _unit(tangent * np.sqrt(1 - c[:, None] ** 2) + n * c[:, None])
+    u = rng.random((N, 3))
+    mat = _material(_abi.MAT_DIELECTRIC, (0, 0, 0), ior)
+    d_out, w, ok = be.material_probe(mat, d, n, u, precision=api.PRECISION_F64)
+    ref, goes_on = _oracle(O, mat, d, n, u)
+    dn = np.einsum("ij,ij->i", d, n)
+    inside = dn > 0
+    F = np.array([O.fresnel(abs(dn[i]), ior if inside[i] else 1.0, 1.0 if inside[i] else ior) for i in range(N)])
+    clear = (np.abs(u[:, 0] - F) > 1e-9) & (np.abs(np.abs(dn) - 5e-4) > 1e-5)
+    assert np.array_equal(ok[clear], goes_on[clear])
+    grazing_refracted = 0
+    for i in np.nonzero(clear)[0]:
+        if ref[i] is None or not goes_on[i]:
+            continue
+        # (with equal indices F is pure rounding noise, ~1e-18: compared absolutely)
+        assert np.allclose(w[i], ref[i]["weight"], rtol=1e-7, atol=1e-12), (i, dn[i], w[i], ref[i]["weight"])
+        assert np.allclose(d_out[i], ref[i]["d_out"], atol=1e-11, rtol=0)
+        if abs(dn[i]) < 4.5e-4 and u[i, 0] >= F[i]:
+            grazing_refracted += 1
+            assert np.allclose(w[i], F[i] / (1 - F[i]), rtol=1e-6, atol=1e-12)  # the reflect formula over the refract probability
+            assert not np.allclose(w[i], 1.0, rtol=1e-3)                         # ... and not 1 / eta^2
+    assert grazing_refracted > 100
+    # the product kernels: same code, f32 -- F itself is rounding noise this close to the surface, so only sanity is asked
+    d32, w32, ok32 = be.material_probe(mat, d, n, u, precision=api.PRECISION_F32)
+    assert np.all(np.isfinite(w32)) and np.all(np.isfinite(d32)) and np.all(w32 >= 0)
+    steep = clear & (np.abs(dn) > 2e-3) & (np.abs(u[:, 0] - F) > 1e-3)
+    assert np.array_equal(ok32[steep], goes_on[steep])
+
+
 def test_emissive_does_not_scatter(gpu):  # src/material.rs:44-46
     api, be = gpu
     d, n, u = _inputs(5)

@@ -60,3 +60,37 @@ def test_reference_flag_names_compress_and_upload(tmp_path):
     assert e["image"] == "render_low_quality.jpg" and e["png"] == "render_low_quality.png"
     assert (out / "cornell box" / e["image"]).exists() and (out / "cornell box" / e["png"]).exists()
     assert "render_low_quality.jpg" in (out / "report.html").read_text()
+
+
+THREE_FLAGS = '''#!%s
+import sys
+from PIL import Image
+# the reference's command line: exactly -s / -r / -o (src/main.rs:25-34), no --help text that names other flags,
+# and anything else is an error
+args = sys.argv[1:]
+if args == ["--help"]:
+    print("Usage: rust-ray-tracer --scene-config <SCENE_CONFIG> --render-config <RENDER_CONFIG> --output <OUTPUT>")
+    sys.exit(0)
+known = {"--scene-config", "--render-config", "--output", "-s", "-r", "-o"}
+opts = dict(zip(args[0::2], args[1::2]))
+if len(args) != 6 or set(opts) - known:
+    print("error: unexpected argument", file=sys.stderr)
+    sys.exit(2)
+Image.new("RGB", (8, 6), (10, 20, 30)).save(opts.get("--output") or opts["-o"])
+'''
+
+
+def test_a_binary_with_only_the_reference_flags_runs_unchanged(tmp_path):
+    """--bin pointing at a renderer that has the reference's three flags and nothing else: the harness must not hand it
+    a flag of this build's own."""
+    fake = tmp_path / "three_flag_rrt"
+    fake.write_text(THREE_FLAGS % sys.executable)
+    fake.chmod(fake.stat().st_mode | stat.S_IXUSR)
+    cfg = tmp_path / "tasks.yml"
+    cfg.write_text(TASKS)
+    out = tmp_path / "report"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "ci", "gen_report.py"), "--bin", str(fake), "--config", str(cfg),
+                        "--output_dir", str(out), "--no_compress"], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    e = json.load(open(out / "report.json"))["tasks"][0]["renders"][0]
+    assert e["returncode"] == 0 and e["image"] == "render_low_quality.png" and "stats" not in e

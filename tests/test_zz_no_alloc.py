@@ -26,8 +26,16 @@ def test_static_equals_allocating_entry_point_twice(gpu, O):
         for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH):
             want_big = be.intersect(sc, o_big, d_big, precision=prec, accel=accel)   # also makes scene (and tree) resident
             want_small = be.intersect(sc, o_small, d_small, precision=prec, accel=accel)
+            import torch
+
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info(0)[0]   # hipMemGetInfo: what the device has free, all processes
             got_big = be.intersect_static(sc, o_big, d_big, precision=prec, accel=accel)
+            free_mid = torch.cuda.mem_get_info(0)[0]
             got_small = be.intersect_static(sc, o_small, d_small, precision=prec, accel=accel)
+            # the entry point's defining property: no device memory is taken, during or after the calls (the GPU box
+            # runs this process alone, so nothing else moves the figure)
+            assert torch.cuda.mem_get_info(0)[0] == free_before == free_mid, (prec, accel)
             assert _same(got_big, want_big), (prec, accel)
             assert _same(got_small, want_small), (prec, accel)
             assert (want_big[0] >= 0).sum() > 1000 and (want_big[0] < 0).sum() > 0
