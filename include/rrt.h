@@ -66,15 +66,17 @@ typedef enum rrt_sampler_type { RRT_SAMPLER_RANDOM = 0, RRT_SAMPLER_STRATIFIED =
 typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_precision;
 
 /* How closest-hit walks the primitives.  LINEAR is the reference's scan (src/scene.rs:35-47), wave-uniform.
- * LBVH and SAH are two builders of one tree format (4-wide nodes, 8-bit child boxes; unbounded planes and quads
- * that are not planar are scanned beside the tree), both returning the primitive and t the scan returns:
- *   LBVH  built on the GPU: primitives in Morton order, clustered bottom-up (neighbours whose union has the
- *         smallest box merge first); ~0.45 s per million primitives including the upload;
- *   SAH   binned surface-area-heuristic tree built top-down by up to 16 host threads (~0.5 s per million
- *         primitives), about a tenth fewer traversal steps per ray.
- * AUTO = LINEAR for scenes of up to 72 primitives (where it is the fastest), SAH otherwise.  A scene keeps every
- * tree it was asked for (per device) until rrt_scene_destroy. */
-typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2, RRT_ACCEL_SAH = 3 } rrt_accel;
+ * The other three are builders of one tree format (4-wide nodes, 8-bit child boxes; unbounded planes and quads
+ * that are not planar are scanned beside the tree), all returning the primitive and t the scan returns:
+ *   SAH_GPU  binned surface-area-heuristic tree built top-down ON THE GPU, level by level (one work-group per range,
+ *            16 bins along four cut coordinates, ranges of up to 32 primitives by an exact sweep);
+ *   SAH      the same tree built by up to 16 host threads (~0.5 s per million primitives): the implementation the GPU
+ *            builder is checked against (same cuts, same tree);
+ *   LBVH     built on the GPU: primitives in Morton order, clustered bottom-up (neighbours whose union has the
+ *            smallest box merge first); about a tenth more traversal steps per ray.
+ * AUTO = LINEAR for scenes of up to 72 primitives (where it is the fastest), SAH_GPU otherwise.  A scene keeps every
+ * tree it was asked for (per device) until rrt_scene_destroy.  rrt_stats.accel_used says which one a call walked. */
+typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBVH = 2, RRT_ACCEL_SAH = 3, RRT_ACCEL_SAH_GPU = 4 } rrt_accel;
 
 /* Which kernel organisation renders.  FUSED keeps a path in registers for
  * all of its bounces and refills finished lanes with new camera samples;

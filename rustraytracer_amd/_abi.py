@@ -18,7 +18,7 @@ PRIM_SPHERE, PRIM_PLANE, PRIM_TRIANGLE, PRIM_QUAD = 0, 1, 2, 3
 MAT_EMISSIVE, MAT_LAMBERTIAN, MAT_PHONG, MAT_REFLECTOR, MAT_DIELECTRIC = 0, 1, 2, 3, 4
 SAMPLER_RANDOM, SAMPLER_STRATIFIED = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
-ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH, ACCEL_SAH = 0, 1, 2, 3
+ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH, ACCEL_SAH, ACCEL_SAH_GPU = 0, 1, 2, 3, 4
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
 RENDER_NEE = 1  # rrt_render_flags
 INTERSECT_STATIC_MAX_RAYS = 65536

@@ -192,7 +192,7 @@ struct DeviceScene {
     rrt::LightView<float> l32{};
     rrt::LightView<double> l64{};
     // One tree per builder (rrt_accel): [0] the cluster tree built on the GPU, [1] the surface-area tree built on the
-    // host.  v32 / v64 themselves never point at a tree: every call makes its own copy of the view and puts the tree
+    // host, [2] the surface-area tree built on the GPU.  v32 / v64 themselves never point at a tree: every call makes its own copy of the view and puts the tree
     // it asked for into that copy (with_tree), so two host threads that use one scene with different builders never
     // see each other's choice.
     struct Tree {
@@ -205,7 +205,7 @@ struct DeviceScene {
         const int32_t* bvh_prim = nullptr;
         const int32_t* linear_prim = nullptr;
         int32_t n_bvh_prims = 0, n_linear_prims = 0;
-    } tree[2];
+    } tree[3];
     int n_unbounded_lights = 0;  // emissive planes: next-event estimation cannot sample them
     ~DeviceScene() {
         if (device >= 0) {
@@ -599,6 +599,23 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
         bool on_host = kind == 1;
         if (kind == 1) {
             if ((rc = host_tree(false)) != RRT_OK) return rc;
+        } else if (kind == 2) {
+            // the builder's fourth cut coordinate, as SahBuilder::build computes it (so that both bin the same numbers)
+            std::vector<float> size((size_t)n);
+            for (int i = 0; i < n; ++i) {
+                rrt::SahBox b;
+                b.clear();
+                b.grow(lo.data() + 3 * (size_t)i, hi.data() + 3 * (size_t)i);
+                size[(size_t)i] = std::log2(std::max(b.half_area(), 1e-30f));
+            }
+            DevBuf dlo, dhi, dsize;
+            HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));
+            HIP_TRY(dhi.alloc(sizeof(float) * 3 * n));
+            HIP_TRY(dsize.alloc(sizeof(float) * n));
+            HIP_TRY(hipMemcpyAsync(dlo.p, lo.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
+            HIP_TRY(hipMemcpyAsync(dhi.p, hi.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
+            HIP_TRY(hipMemcpyAsync(dsize.p, size.data(), sizeof(float) * n, hipMemcpyHostToDevice, be->stream));
+            HIP_TRY(rrt::gsah_tree((const float*)dlo.p, (const float*)dhi.p, (const float*)dsize.p, n, (rrt::WideNode*)nodes, (int*)slots, be->stream, &depth));
         } else {
             DevBuf dlo, dhi;
             HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));
@@ -652,12 +669,14 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
     return RRT_OK;
 }
 
-// Which tree an rrt_accel value means: -1 none (linear scan), 0 cluster tree (GPU), 1 surface-area tree (host).
+// Which tree an rrt_accel value means: -1 none (linear scan), 0 cluster tree (GPU), 1 surface-area tree (host), 2 surface-area tree (GPU).
 int tree_kind(const rrt_scene* sc, uint32_t accel) {
     if (accel == RRT_ACCEL_LBVH) return 0;
     if (accel == RRT_ACCEL_SAH) return 1;
-    return accel == RRT_ACCEL_AUTO && sc->prims.size() > kAutoBvhThreshold ? 1 : -1;
+    if (accel == RRT_ACCEL_SAH_GPU) return 2;
+    return accel == RRT_ACCEL_AUTO && sc->prims.size() > kAutoBvhThreshold ? 2 : -1;
 }
+const uint32_t kAccelOfKind[3] = {RRT_ACCEL_LBVH, RRT_ACCEL_SAH, RRT_ACCEL_SAH_GPU};
 
 // AUTO: the surface-area tree for scenes too large for the wave-uniform scan; LBVH, SAH: that tree; LINEAR: none.
 // *kind = the tree the call walks (-1: none); *built_now = whether this call built it.
@@ -695,7 +714,7 @@ int closest_hit_call(rrt_backend* be, const rrt_scene* scene, uint32_t precision
     if (rc != RRT_OK) return rc;
     if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
     if (precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", precision);
-    if (accel > RRT_ACCEL_SAH) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
+    if (accel > RRT_ACCEL_SAH_GPU) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
     if (n == 0) return RRT_OK;
     if (!a || !b || !object_id || !prim_id || !t) return fail(RRT_ERR_INVALID, "NULL array argument");
     if (scene->prims.empty()) {
@@ -756,7 +775,7 @@ int validate_render_desc(const rrt_render_desc* d) {
     if (d->sample_end <= d->sample_begin) return fail(RRT_ERR_INVALID, "empty sample range");
     if (d->sample_end > 0x7fffffffull) return fail(RRT_ERR_INVALID, "sample index beyond 2^31");
     if (d->precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", d->precision);
-    if (d->accel > RRT_ACCEL_SAH) return fail(RRT_ERR_INVALID, "unknown accel %u", d->accel);
+    if (d->accel > RRT_ACCEL_SAH_GPU) return fail(RRT_ERR_INVALID, "unknown accel %u", d->accel);
     if (d->pipeline > RRT_PIPELINE_WAVEFRONT) return fail(RRT_ERR_INVALID, "unknown pipeline %u", d->pipeline);
     if (d->flags & ~(uint32_t)RRT_RENDER_NEE) return fail(RRT_ERR_INVALID, "unknown render flags 0x%x", d->flags);
     if ((d->flags & RRT_RENDER_NEE) && d->pipeline == RRT_PIPELINE_WAVEFRONT)
@@ -1100,7 +1119,7 @@ int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t preci
     if (rc != RRT_OK) return rc;
     if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
     if (precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", precision);
-    if (accel > RRT_ACCEL_SAH) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
+    if (accel > RRT_ACCEL_SAH_GPU) return fail(RRT_ERR_INVALID, "unknown accel %u", accel);
     if (n > (size_t)RRT_INTERSECT_STATIC_MAX_RAYS)
         return fail(RRT_ERR_INVALID, "rrt_intersect_static takes at most %d rays per call, got %zu (split the batch, or use rrt_intersect)",
                     RRT_INTERSECT_STATIC_MAX_RAYS, n);
@@ -1232,7 +1251,7 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         stats->node_tests = counters[rrt::COUNTER_NODE_TESTS];
         for (int k = 0; k < 5; ++k) stats->bounces[k] = counters[rrt::COUNTER_BOUNCE0 + k];
         stats->nonfinite = counters[rrt::COUNTER_NONFINITE];
-        stats->accel_used = kind < 0 ? RRT_ACCEL_LINEAR : (kind == 0 ? RRT_ACCEL_LBVH : RRT_ACCEL_SAH);
+        stats->accel_used = kind < 0 ? (uint32_t)RRT_ACCEL_LINEAR : kAccelOfKind[kind];
         stats->pipeline_used = wavefront ? RRT_PIPELINE_WAVEFRONT : RRT_PIPELINE_FUSED;
         stats->tree_depth = kind >= 0 ? (uint32_t)ds->tree[kind].depth : 0u;
         stats->tree_built = built_now ? 1u : 0u;

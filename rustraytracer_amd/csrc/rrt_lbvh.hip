@@ -93,7 +93,7 @@ __device__ void write_wide_node(const float (*lo)[3], const float (*hi)[3], cons
 // handles the marked nodes and marks their internal children, the host repeats it until a launch marks nothing.
 __global__ void __launch_bounds__(256)
 widen_kernel(const BvhNode* __restrict__ nodes, int n, WideNode* __restrict__ wide, int* __restrict__ state,
-             int* __restrict__ marked) {
+             int* __restrict__ marked, unsigned int* __restrict__ level_of, unsigned int level) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     if (__hip_atomic_load(&state[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) return;
@@ -122,6 +122,7 @@ widen_kernel(const BvhNode* __restrict__ nodes, int n, WideNode* __restrict__ wi
     if ((shape & SAH_OPEN_RIGHT_0) && right1 >= 0 && child[1] >= 0 && k < 4) open(1);
     if ((shape & SAH_OPEN_RIGHT_1) && right1 >= 0 && child[right1] >= 0 && k < 4) open(right1);
     write_wide_node(lo, hi, child, k, &wide[i]);
+    level_of[i] = level;
     int any = 0;
     for (int c = 0; c < k; ++c)
         if (child[c] >= 0) {
@@ -136,6 +137,21 @@ __global__ void __launch_bounds__(256) finished_flag_kernel(const int* __restric
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     flag[i] = state[i] == 2 ? 1 : 0;
+}
+
+// Level-major packing order: key = the node's level in the wide tree (unreachable binary nodes sort behind everything).
+__global__ void __launch_bounds__(256)
+level_key_kernel(const int* __restrict__ state, unsigned int* __restrict__ level_of, unsigned int* __restrict__ index, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    level_of[i] = state[i] == 2 ? (level_of[i] < 0xfffeu ? level_of[i] : 0xfffeu) : 0xffffu;
+    index[i] = (unsigned int)i;
+}
+__global__ void __launch_bounds__(256)
+rank_to_index_kernel(const unsigned int* __restrict__ order, int n, int* __restrict__ new_index) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n - 1) return;
+    new_index[order[j]] = j;  // (unreachable nodes get ranks behind the reachable ones; nobody links to them)
 }
 
 // Packs the reachable wide nodes to the front of `out`, in index order (which is the sorted order of
@@ -168,14 +184,19 @@ pack_leaves_kernel(const PrimRec<R>* __restrict__ prims, const int* __restrict__
 
 // d_wide = the wide nodes of the m binary nodes at d_nodes (marked, node 0 the root), packed; *depth = the levels of
 // wide nodes (what bounds a traversal stack: a walk holds at most three entries per level).  Synchronises the stream.
-static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide, hipStream_t stream, int* depth) {
+// level_major = false: packed in the order of the binary nodes' numbers (the builders that number the top of the tree
+// first); true: level by level from the root, by number inside a level (for a builder that numbers depth-first: the
+// traversal kernels keep the first wide nodes of the array in LDS, and those should be the top of the tree).
+static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide, hipStream_t stream, int* depth, bool level_major) {
     const int n = m + 1;  // the kernels take the primitive count of a full binary tree
     hipError_t e;
     WideNode* wide_tmp = nullptr;
     int *state = nullptr, *flag = nullptr, *new_index = nullptr, *marked = nullptr;
+    unsigned int *level_of = nullptr, *level_sorted = nullptr, *index_in = nullptr, *index_sorted = nullptr;
     void* temp = nullptr;
     auto cleanup = [&]() {
         (void)hipFree(wide_tmp); (void)hipFree(state); (void)hipFree(flag); (void)hipFree(new_index); (void)hipFree(marked);
+        (void)hipFree(level_of); (void)hipFree(level_sorted); (void)hipFree(index_in); (void)hipFree(index_sorted);
         (void)hipFree(temp);
     };
 #define LBVH_TRY(x) do { e = (x); if (e != hipSuccess) { cleanup(); return e; } } while (0)
@@ -184,6 +205,7 @@ static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide
     LBVH_TRY(hipMalloc(&flag, sizeof(int) * n));
     LBVH_TRY(hipMalloc(&new_index, sizeof(int) * n));
     LBVH_TRY(hipMalloc(&marked, sizeof(int)));
+    LBVH_TRY(hipMalloc(&level_of, sizeof(unsigned int) * n));
     LBVH_TRY(hipMemsetAsync(state, 0, sizeof(int) * n, stream));
     const int one = 1;
     LBVH_TRY(hipMemcpyAsync(state, &one, sizeof(int), hipMemcpyHostToDevice, stream));
@@ -191,7 +213,7 @@ static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide
     for (int round = 0;; ++round) {  // one launch per level of the wide tree
         int again = 0;
         LBVH_TRY(hipMemsetAsync(marked, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(widen_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp, state, marked);
+        hipLaunchKernelGGL(widen_kernel, grid, block, 0, stream, d_nodes, n, wide_tmp, state, marked, level_of, (unsigned int)round);
         LBVH_TRY(hipGetLastError());
         LBVH_TRY(hipMemcpyAsync(&again, marked, sizeof(int), hipMemcpyDeviceToHost, stream));
         LBVH_TRY(hipStreamSynchronize(stream));
@@ -203,9 +225,22 @@ static hipError_t widen_and_pack(const BvhNode* d_nodes, int m, WideNode* d_wide
     hipLaunchKernelGGL(finished_flag_kernel, grid, block, 0, stream, state, n, flag);
     LBVH_TRY(hipGetLastError());
     size_t scan_bytes = 0;
-    LBVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, new_index, 0, (size_t)m, rocprim::plus<int>(), stream));
-    LBVH_TRY(hipMalloc(&temp, scan_bytes ? scan_bytes : 16));
-    LBVH_TRY(rocprim::exclusive_scan(temp, scan_bytes, flag, new_index, 0, (size_t)m, rocprim::plus<int>(), stream));
+    if (level_major) {
+        LBVH_TRY(hipMalloc(&level_sorted, sizeof(unsigned int) * n));
+        LBVH_TRY(hipMalloc(&index_in, sizeof(unsigned int) * n));
+        LBVH_TRY(hipMalloc(&index_sorted, sizeof(unsigned int) * n));
+        hipLaunchKernelGGL(level_key_kernel, grid, block, 0, stream, state, level_of, index_in, n);
+        LBVH_TRY(hipGetLastError());
+        LBVH_TRY(rocprim::radix_sort_pairs(nullptr, scan_bytes, level_of, level_sorted, index_in, index_sorted, (size_t)m, 0, 16, stream));
+        LBVH_TRY(hipMalloc(&temp, scan_bytes ? scan_bytes : 16));
+        LBVH_TRY(rocprim::radix_sort_pairs(temp, scan_bytes, level_of, level_sorted, index_in, index_sorted, (size_t)m, 0, 16, stream));
+        hipLaunchKernelGGL(rank_to_index_kernel, grid, block, 0, stream, index_sorted, n, new_index);
+        LBVH_TRY(hipGetLastError());
+    } else {
+        LBVH_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, flag, new_index, 0, (size_t)m, rocprim::plus<int>(), stream));
+        LBVH_TRY(hipMalloc(&temp, scan_bytes ? scan_bytes : 16));
+        LBVH_TRY(rocprim::exclusive_scan(temp, scan_bytes, flag, new_index, 0, (size_t)m, rocprim::plus<int>(), stream));
+    }
     hipLaunchKernelGGL(compact_kernel, grid, block, 0, stream, wide_tmp, flag, new_index, n, d_wide);
     LBVH_TRY(hipGetLastError());
     LBVH_TRY(hipStreamSynchronize(stream));
@@ -244,7 +279,7 @@ hipError_t lbvh_build(const float* d_lo, const float* d_hi, int n, const float s
     LBVH_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, index_in, index_out, (size_t)n, 0, 63,
                                        stream));
     LBVH_TRY(ploc_build(d_lo, d_hi, d_prim_of_slot, n, d_nodes, stream));
-    LBVH_TRY(widen_and_pack(d_nodes, n - 1, d_wide, stream, depth));
+    LBVH_TRY(widen_and_pack(d_nodes, n - 1, d_wide, stream, depth, false));
 #undef LBVH_TRY
     cleanup();
     return hipSuccess;
@@ -256,7 +291,20 @@ hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, WideNode* d_wide, 
     BvhNode* d_nodes = nullptr;
     hipError_t e = hipMalloc(&d_nodes, sizeof(BvhNode) * (size_t)m);
     if (e == hipSuccess) e = hipMemcpyAsync(d_nodes, h_nodes, sizeof(BvhNode) * (size_t)m, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = widen_and_pack(d_nodes, m, d_wide, stream, depth);
+    if (e == hipSuccess) e = widen_and_pack(d_nodes, m, d_wide, stream, depth, false);
+    (void)hipFree(d_nodes);
+    return e;
+}
+
+// The whole surface-area tree on the GPU (rrt_gsah.hip): binary tree, wide nodes, packed level by level.
+hipError_t gsah_tree(const float* d_lo, const float* d_hi, const float* d_size, int n, WideNode* d_wide, int* d_prim_of_slot,
+                     hipStream_t stream, int* depth) {
+    if (n < 2 || n > BVH_MAX_PRIMS) return hipErrorInvalidValue;
+    BvhNode* d_nodes = nullptr;
+    hipError_t e = hipMalloc(&d_nodes, sizeof(BvhNode) * (size_t)(n - 1));
+    int levels = 0;
+    if (e == hipSuccess) e = gsah_build(d_lo, d_hi, d_size, n, d_nodes, d_prim_of_slot, stream, &levels);
+    if (e == hipSuccess) e = widen_and_pack(d_nodes, n - 1, d_wide, stream, depth, true);
     (void)hipFree(d_nodes);
     return e;
 }

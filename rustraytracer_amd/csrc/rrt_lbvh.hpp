@@ -22,6 +22,16 @@ hipError_t ploc_build(const float* d_lo, const float* d_hi, const int* d_prim_of
 // Synchronises the stream.
 hipError_t bvh_widen_host_tree(const BvhNode* h_nodes, int m, WideNode* d_wide, hipStream_t stream, int* depth);
 
+// The binary surface-area tree built on the GPU (rrt_gsah.hip): the tree SahBuilder (rrt_sah.hpp) makes from the same
+// boxes -- same cut coordinates, bins, costs and tie rules -- level by level, one work-group per range.  d_size[i] = log2 of
+// the half area of box i, computed by the host like SahBuilder does.  d_nodes: n - 1 records, node 0 the root, a node's
+// children numbered above it (depth first), wide-node marks in BvhNode::pad0.  Needs n >= 2.  Synchronises the stream.
+hipError_t gsah_build(const float* d_lo, const float* d_hi, const float* d_size, int n, BvhNode* d_nodes, int* d_prim_of_slot,
+                      hipStream_t stream, int* levels);
+// ... and its wide nodes, packed level by level from the root (the first wide nodes of the array are the top of the tree).
+hipError_t gsah_tree(const float* d_lo, const float* d_hi, const float* d_size, int n, WideNode* d_wide, int* d_prim_of_slot,
+                     hipStream_t stream, int* depth);
+
 // out[slot] = leaf record of primitive prim_of_slot[slot] (scan-order indices), n entries.
 hipError_t lbvh_pack_leaves(const PrimRec<float>* prims, const int* prim_of_slot, int n, LeafRec<float>* out, hipStream_t s);
 hipError_t lbvh_pack_leaves(const PrimRec<double>* prims, const int* prim_of_slot, int n, LeafRec<double>* out, hipStream_t s);

@@ -42,6 +42,9 @@ struct SahBox {
 // the choice goes into BvhNode::pad0 as SAH_OPEN_* bits.  Opening the largest child first, as the widening kernel
 // does on its own, ends 4 % above this on a million-triangle mesh.
 RRT_SAH_HD inline void sah_mark_node(BvhNode* nodes, float* f, size_t k) {
+#if defined(__clang__)
+#pragma clang fp contract(off)  // host and device must price a node alike: every product and sum rounded
+#endif
     BvhNode& N = nodes[k];
     auto area = [](const BvhNode& P, int w) {
         const float* l = w ? P.lo1 : P.lo0;

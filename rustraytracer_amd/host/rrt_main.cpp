@@ -27,7 +27,7 @@ const char* kUsage =
     "                                       evenly, the radiance sums are added on the host\n"
     "      --seed <N>                       sampler seed (overrides `seed` of the render config)\n"
     "      --precision <f32|f64>            arithmetic of the kernels [default: f32]\n"
-    "      --accel <auto|linear|lbvh|sah>   closest-hit structure [default: auto]\n"
+    "      --accel <auto|linear|lbvh|sah|sah_gpu>  closest-hit structure [default: auto]\n"
     "      --pipeline <auto|fused|wavefront> kernel organisation [default: auto]\n"
     "      --next-event                     sample the lights at every Lambertian / Phong vertex (next-event estimation:\n"
     "                                       same image in the mean, less noise with small lights; not the reference's estimator)\n"
@@ -106,8 +106,8 @@ Args parse_args(int argc, char** argv) {
             static const char* const n[] = {"f32", "f64"};
             a.precision = choice(arg, value(), n, 2);
         } else if (arg == "--accel") {
-            static const char* const n[] = {"auto", "linear", "lbvh", "sah"};
-            a.accel = choice(arg, value(), n, 4);
+            static const char* const n[] = {"auto", "linear", "lbvh", "sah", "sah_gpu"};
+            a.accel = choice(arg, value(), n, 5);
         } else if (arg == "--pipeline") {
             static const char* const n[] = {"auto", "fused", "wavefront"};
             a.pipeline = choice(arg, value(), n, 3);

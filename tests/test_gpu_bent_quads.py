@@ -27,7 +27,7 @@ def test_bent_quads_against_the_oracle(gpu, O, name):
     margin = _margin(flat, quads, o, d)
     hit = ref[0] >= 0
     assert hit.sum() > 0.3 * len(o) and (~hit).sum() > 50
-    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH):
+    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH, api.ACCEL_SAH_GPU):
         oid, pid, t = be.intersect(sc, o, d, precision=api.PRECISION_F64, accel=accel)
         assert np.array_equal(oid, ref[0]) and np.array_equal(pid, ref[1]), (name, accel)
         assert np.all(np.abs(t[hit] - ref[2][hit]) <= 1e-11 * np.abs(ref[2][hit]))
@@ -54,7 +54,7 @@ def test_scan_and_tree_agree_bit_for_bit_on_bent_quads(gpu):
         sc = api.Scene(flat)
         for prec in (api.PRECISION_F64, api.PRECISION_F32):
             a = be.intersect(sc, o, d, precision=prec, accel=api.ACCEL_LINEAR)
-            for tree in (api.ACCEL_LBVH, api.ACCEL_SAH):
+            for tree in (api.ACCEL_LBVH, api.ACCEL_SAH, api.ACCEL_SAH_GPU):
                 b = be.intersect(sc, o, d, precision=prec, accel=tree)
                 assert all(np.array_equal(x, y) for x, y in zip(a, b)), (name, prec, tree)
 

@@ -169,13 +169,13 @@ def test_cli_accel_names(tmp_path):
     rc_path = tmp_path / "r.toml"
     rc_path.write_text(RENDER.format(sampler="Stratified", strata="x_strata = 8\ny_strata = 8", wb=""))
     outs = {}
-    for name in ("linear", "lbvh", "sah"):
+    for name in ("linear", "lbvh", "sah", "sah_gpu"):
         out, stats = tmp_path / (name + ".png"), tmp_path / (name + ".json")
         r = subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(out), "--stats-json", str(stats), "--accel", name],
                            capture_output=True, text=True, timeout=120, cwd=ROOT)
         assert r.returncode == 0, r.stderr
         outs[name] = (np.asarray(Image.open(out).convert("RGB")).astype(int), json.load(open(stats)))
-    for name in ("lbvh", "sah"):
+    for name in ("lbvh", "sah", "sah_gpu"):
         assert outs[name][1]["rays"] == outs["linear"][1]["rays"] and outs[name][1]["node_tests"] > 0
         assert np.abs(outs[name][0] - outs["linear"][0]).max() <= 1
     assert outs["linear"][1]["node_tests"] == 0

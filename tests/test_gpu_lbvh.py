@@ -16,7 +16,7 @@ import make_mesh  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-TREES = (_abi.ACCEL_LBVH, _abi.ACCEL_SAH)
+TREES = (_abi.ACCEL_LBVH, _abi.ACCEL_SAH, _abi.ACCEL_SAH_GPU)
 
 
 def mesh_scene(n_tri, seed=2, with_quads=False):
@@ -302,3 +302,33 @@ def test_million_triangle_scene_tree_equals_scan(gpu, cfg, O):
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     h = ref[0] >= 0
     assert np.all(np.abs(got[2][h] - ref[2][h]) <= 1e-9 * ref[2][h])
+
+
+@pytest.mark.parametrize("name", ["mesh3k", "mesh60k", "mesh200k_quads", "cornell_cube", "all_prims"])
+def test_gpu_built_surface_area_tree_is_the_host_builders_tree(gpu, cfg, cornell, name):
+    """RRT_ACCEL_SAH_GPU (what AUTO builds) makes its cuts with the host builder's rules -- same cut coordinates, bins,
+    cost, tie order, the exact sweep for ranges of up to 32 primitives -- so it must arrive at the same tree: a render
+    walks the same number of nodes and tests the same number of primitives through either, ray for ray, and the
+    trees are equally deep.  (The node numbering differs, which no count sees.)"""
+    api, be = gpu
+    flat = {"mesh3k": lambda: mesh_scene(3000), "mesh60k": lambda: mesh_scene(60000, seed=5),
+            "mesh200k_quads": lambda: mesh_scene(200000, seed=9, with_quads=False),
+            "cornell_cube": lambda: cornell_with_cube(cfg, cornell), "all_prims": S.all_prims_scene}[name]()
+    sc = api.Scene(flat)
+    rc = cfg.stratified_config(96, 96, 2, 2, seed=61)
+    res = {}
+    for accel in (api.ACCEL_SAH, api.ACCEL_SAH_GPU):
+        img, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64, accel=accel, pipeline=api.PIPELINE_FUSED))
+        assert st["accel_used"] == accel and st["tree_built"] == 1 and st["stack_overflows"] == 0
+        res[accel] = (img, st)
+    host, dev = res[api.ACCEL_SAH][1], res[api.ACCEL_SAH_GPU][1]
+    print(name, "node tests", host["node_tests"], dev["node_tests"], "prim tests", host["prim_tests"], dev["prim_tests"],
+          "depth", host["tree_depth"], dev["tree_depth"], "build ms", host["tree_build_ms"], dev["tree_build_ms"])
+    assert host["rays"] == dev["rays"] and host["node_tests"] > 0
+    assert dev["node_tests"] == host["node_tests"] and dev["prim_tests"] == host["prim_tests"]
+    assert dev["tree_depth"] == host["tree_depth"]
+    assert np.allclose(res[api.ACCEL_SAH][0], res[api.ACCEL_SAH_GPU][0], rtol=1e-6, atol=1e-9)
+    # AUTO takes the GPU builder (for scenes large enough for a tree at all)
+    _, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F32))
+    if flat.n_prims > 72:
+        assert st["accel_used"] == api.ACCEL_SAH_GPU and st["tree_built"] == 0

@@ -55,7 +55,7 @@ def test_every_primitive_and_material_same_paths(gpu, O, cfg):
 def test_same_paths_through_the_tree(gpu, O, cfg, cornell):
     """Closest hit through either tree instead of the scan: the same primitive and t for every ray, so the same image."""
     api, be = gpu
-    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH):
+    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH, api.ACCEL_SAH_GPU):
         _compare(api, be, O, cfg, cornell, cfg.stratified_config(64, 64, 4, 4, seed=31), max_bad=3, accel=tree)
         _compare(api, be, O, cfg, S.all_prims_scene(), cfg.stratified_config(64, 48, 4, 4, max_depth=8, seed=32), max_bad=4,
                  accel=tree)
@@ -214,7 +214,7 @@ def test_ties_and_degenerate_inputs_same_paths(gpu, O, cfg):
     api, be = gpu
     flat = _nasty_scene()
     rc = cfg.stratified_config(96, 72, 4, 4, min_depth=1, max_depth=10, seed=81)
-    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH):
+    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH, api.ACCEL_SAH_GPU):
         bad = _compare(api, be, O, cfg, flat, rc, max_bad=6, accel=accel)
         print("accel", accel, "f64 pixels off:", bad)
     frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_FUSED, "nasty fused")

@@ -30,7 +30,7 @@ def _rays_through(rng, anchor, reach, n=RAYS):
 
 
 def _modes(api):
-    return [(prec, accel) for prec in (api.PRECISION_F64, api.PRECISION_F32) for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH)]
+    return [(prec, accel) for prec in (api.PRECISION_F64, api.PRECISION_F32) for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH, api.ACCEL_SAH_GPU)]
 
 
 def test_sphere_geometric_equals_analytic(gpu):  # src/shapes/sphere.rs:129-179

@@ -40,11 +40,11 @@ def test_same_paths_as_fused_linear(gpu, cfg, scenes, name):
 def test_same_paths_as_fused_lbvh(gpu, cfg, cornell):
     api, be = gpu
     sc = api.Scene(cornell)
-    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH):
+    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH, api.ACCEL_SAH_GPU):
         same_paths(*both(api, be, sc, cfg.stratified_config(96, 96, 4, 4), tree))
     # all primitive types and all materials, planes beside the tree
     sc = api.Scene(S.all_prims_scene())
-    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH):
+    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH, api.ACCEL_SAH_GPU):
         same_paths(*both(api, be, sc, cfg.stratified_config(80, 60, 4, 4), tree))
 
 

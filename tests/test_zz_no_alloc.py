@@ -23,7 +23,7 @@ def test_static_equals_allocating_entry_point_twice(gpu, O):
     assert 40000 < len(o_big) <= _abi.INTERSECT_STATIC_MAX_RAYS
     o_small, d_small = S.secondary_rays(flat, O, 700, seed=22)
     for prec in (api.PRECISION_F32, api.PRECISION_F64):
-        for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH):
+        for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH, api.ACCEL_SAH, api.ACCEL_SAH_GPU):
             want_big = be.intersect(sc, o_big, d_big, precision=prec, accel=accel)   # also makes scene (and tree) resident
             want_small = be.intersect(sc, o_small, d_small, precision=prec, accel=accel)
             import torch

@@ -12,7 +12,7 @@ t0 = time.time(); flat = config.load_scene(os.path.join(ROOT, "configs/mesh_1m/s
 t0 = time.time(); sc = api.Scene(flat); print("scene create %.2fs" % (time.time() - t0), flush=True)
 rc = config.stratified_config(W, H, S, S)
 rc.max_depth = int(os.environ.get("C5_MAX_DEPTH", "6"))
-ACCEL = {"lbvh": api.ACCEL_LBVH, "sah": api.ACCEL_SAH, "auto": api.ACCEL_AUTO}[os.environ.get("RRT_C5_ACCEL", "auto")]  # which tree
+ACCEL = {"lbvh": api.ACCEL_LBVH, "sah": api.ACCEL_SAH, "sah_gpu": api.ACCEL_SAH_GPU, "auto": api.ACCEL_AUTO}[os.environ.get("RRT_C5_ACCEL", "auto")]  # which tree
 t0 = time.time(); rgb, st = be.render_accumulate(sc, config.stratified_config(64, 64, 2, 2).render_desc(accel=ACCEL)); print("first call (build) %.2fs" % (time.time() - t0), flush=True)
 for rep in range(2):
     rgb, st = be.render_accumulate(sc, rc.render_desc(accel=ACCEL))
