@@ -78,6 +78,9 @@ def parse_args(argv=None):
     ap.add_argument("--precision", choices=["f32", "f64"], default="f32",
                     help="f32 is the product path; f64 runs the same kernels in the reference's arithmetic type")
     ap.add_argument("--spp-side", type=int, default=0, help="strata per axis (default: the workload's)")
+    ap.add_argument("--exact-hits", action="store_true",
+                    help="RRT_RENDER_EXACT_HITS: every f32 closest-hit query tracked and repeated in f64 where f32 cannot decide "
+                         "(a measurement of that mode's cost; the headline number is quoted without it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args(argv)
 
@@ -278,7 +281,8 @@ def run_rank(args):
         be.set_stream(torch.cuda.current_stream().cuda_stream)
         pipeline = {"auto": api.PIPELINE_AUTO, "fused": api.PIPELINE_FUSED, "wavefront": api.PIPELINE_WAVEFRONT}[args.pipeline]
         precision = api.PRECISION_F64 if args.precision == "f64" else api.PRECISION_F32
-        desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline, precision=precision)
+        desc = rc.render_desc(sample_begin=lo, sample_end=hi, pipeline=pipeline, precision=precision,
+                              flags=api.RENDER_EXACT_HITS if args.exact_hits else 0)
         post = rc.post_desc()
         acc = torch.zeros((rc.height, rc.width, 3), dtype=torch.float32, device="cuda")
         img = torch.zeros((rc.height, rc.width, 3), dtype=torch.uint8, device="cuda")
@@ -390,6 +394,8 @@ def run_rank(args):
                 "tree_depth": st["tree_depth"],
                 "tree_build_ms_first_call": first["tree_build_ms"] if first and first["tree_built"] else None,
                 "stack_overflows": st["stack_overflows"],
+                "exact_hits": bool(args.exact_hits),
+                "exact_redos_per_ray": st["exact_redos"] / max(st["rays"], 1),
                 "reduce": "RCCL sum-reduce of %.1f MB fp32 accumulators to rank 0" % (D.message_bytes(width, height) / 1e6)
                 if world > 1 else "none",
                 "samples_per_step": int(all_samples / args.steps),

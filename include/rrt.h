@@ -92,8 +92,15 @@ typedef enum rrt_pipeline { RRT_PIPELINE_AUTO = 0, RRT_PIPELINE_FUSED = 1, RRT_P
  * on an emissive primitive is sampled (lights chosen in proportion to area x emission, points uniform in area)
  * and connected through a shadow ray; emission found by a scattered ray then counts only after a mirror or
  * dielectric bounce or for the camera ray itself, so every light path is still counted once.  Same expected
- * image, less noise with small lights.  Fused pipeline only; emissive planes (infinite area) are refused. */
-typedef enum rrt_render_flags { RRT_RENDER_NEE = 1 } rrt_render_flags;
+ * image, less noise with small lights.  Fused pipeline only; emissive planes (infinite area) are refused.
+ * RRT_RENDER_EXACT_HITS: the f32 renderer tracks the rounding-error bound of every closest-hit decision (edge
+ * coefficients, |n.d| - 1e-6, t - t_min, the order of two distances) and repeats in f64 the queries in which a decision
+ * lies inside its bound, so that every ray it traces meets the primitive the f64 arithmetic of the reference
+ * (the files under src/shapes) names for THAT ray; rrt_stats.exact_redos counts them.  The path state stays f32, so a path can
+ * still part from the reference's where its f32 ray itself differs from the f64 one.  rrt_intersect and
+ * rrt_trace_primary always work this way in f32 (their f64 input rays are what the repeated queries use).  Fused pipeline
+ * only, f32 only (ignored for f64), not together with RRT_RENDER_NEE. */
+typedef enum rrt_render_flags { RRT_RENDER_NEE = 1, RRT_RENDER_EXACT_HITS = 2 } rrt_render_flags;
 
 /* One primitive in the order the reference's linear scan visits it:
  * objects in [[objects]] order (src/scene.rs:39), faces in file order inside a
@@ -203,7 +210,9 @@ int rrt_backend_set_stream(rrt_backend* backend, void* hip_stream);
 
 /* Scene::intersect (src/scene.rs:35-47) for n arbitrary rays.  origins/dirs are
  * 3n host doubles; results are host arrays of n.  A miss gives ids -1 and
- * t = +inf.  Directions must be unit length, as everywhere in the reference. */
+ * t = +inf.  Directions must be unit length, as everywhere in the reference.
+ * precision = F32 runs the product kernels' f32 tests and repeats in f64 the rays whose decisions f32 cannot settle
+ * within its error bounds (see RRT_RENDER_EXACT_HITS), so the ids are those of the f64 query; t is the f32 distance. */
 int rrt_intersect(rrt_backend* backend, const rrt_scene* scene, uint32_t precision, uint32_t accel,
                   size_t n, const double* origins, const double* dirs,
                   int32_t* object_id, int32_t* prim_id, double* t);

@@ -20,7 +20,7 @@ SAMPLER_RANDOM, SAMPLER_STRATIFIED = 0, 1
 PRECISION_F32, PRECISION_F64 = 0, 1
 ACCEL_AUTO, ACCEL_LINEAR, ACCEL_LBVH, ACCEL_SAH, ACCEL_SAH_GPU = 0, 1, 2, 3, 4
 PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT = 0, 1, 2
-RENDER_NEE = 1  # rrt_render_flags
+RENDER_NEE, RENDER_EXACT_HITS = 1, 2  # rrt_render_flags
 INTERSECT_STATIC_MAX_RAYS = 65536
 
 # numpy views of the plain-data structs (bulk construction of large scenes)

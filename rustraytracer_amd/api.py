@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import (ACCEL_AUTO, ACCEL_LBVH, ACCEL_LINEAR, ACCEL_SAH, ACCEL_SAH_GPU, PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT, RENDER_NEE,  # noqa: F401
+from ._abi import (ACCEL_AUTO, ACCEL_LBVH, ACCEL_LINEAR, ACCEL_SAH, ACCEL_SAH_GPU, PIPELINE_AUTO, PIPELINE_FUSED, PIPELINE_WAVEFRONT, RENDER_NEE, RENDER_EXACT_HITS,  # noqa: F401
                    PRECISION_F32, PRECISION_F64, RrtError)
 
 _dp = C.POINTER(C.c_double)

@@ -191,6 +191,7 @@ struct DeviceScene {
     rrt::SceneView<double> v64{};
     rrt::LightView<float> l32{};
     rrt::LightView<double> l64{};
+    const rrt::ErrRec* err32 = nullptr;  // per-primitive magnitudes for the error bounds of tracked f32 queries, scan order
     // One tree per builder (rrt_accel): [0] the cluster tree built on the GPU, [1] the surface-area tree built on the
     // host, [2] the surface-area tree built on the GPU.  v32 / v64 themselves never point at a tree: every call makes its own copy of the view and puts the tree
     // it asked for into that copy (with_tree), so two host threads that use one scene with different builders never
@@ -359,6 +360,34 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view, rrt
         view.cam_v[k] = (R)sc->camera.vertical[k];
     }
     int rc;
+    if (sizeof(R) == 4) {  // magnitudes for the error bounds of tracked f32 queries (rrt_device.hpp, HitTrack), rounded up
+        std::vector<rrt::ErrRec> err(prims.size());
+        auto up = [](double x) { return std::nextafterf((float)x, INFINITY) * 1.000001f; };
+        for (size_t i = 0; i < prims.size(); ++i) {
+            const double* f = prims[i].f;
+            auto sum3 = [&](int k) { return std::fabs(f[k]) + std::fabs(f[k + 1]) + std::fabs(f[k + 2]); };
+            rrt::ErrRec e;
+            std::memset(&e, 0, sizeof(e));
+            if (prims[i].type == rrt::PRIM_SPHERE) {
+                e.e[0] = up(std::fmax(std::fmax(std::fabs(f[0]), std::fabs(f[1])), std::fabs(f[2])));
+            } else {
+                e.e[0] = up(sum3(0));
+                e.e[1] = up(std::fabs(f[3]));
+                if (prims[i].type != rrt::PRIM_PLANE) {
+                    e.e[2] = up(std::fmax(sum3(4), sum3(8)));
+                    e.e[3] = up(std::fmax(std::fabs(f[7]), std::fabs(f[11])) + 1.0);
+                }
+                if (prims[i].type == rrt::PRIM_QUAD) {
+                    e.e[4] = up(sum3(20));
+                    e.e[5] = up(std::fabs(f[23]));
+                    e.e[6] = up(std::fmax(sum3(12), sum3(16)));
+                    e.e[7] = up(std::fmax(std::fabs(f[15]), std::fabs(f[19])) + 1.0);
+                }
+            }
+            err[i] = e;
+        }
+        if ((rc = upload(ds, err, &ds->err32, stream)) != RRT_OK) return rc;
+    }
     if ((rc = upload(ds, p, &view.prims, stream)) != RRT_OK) return rc;
     if ((rc = upload(ds, s, &view.shade, stream)) != RRT_OK) return rc;
     if ((rc = upload(ds, m, &view.mats, stream)) != RRT_OK) return rc;
@@ -743,7 +772,7 @@ int closest_hit_call(rrt_backend* be, const rrt_scene* scene, uint32_t precision
         HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v64, kind), use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
                                       (int32_t*)doid.p, (int32_t*)dpid.p, (double*)dt.p, be->stream));
     else
-        HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v32, kind), use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
+        HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v32, kind), with_tree(be, ds, ds->v64, kind), ds->err32, use_bvh, primary, n, (const double*)da.p, (const double*)db.p,
                                       (int32_t*)doid.p, (int32_t*)dpid.p, (double*)dt.p, be->stream));
     HIP_TRY(hipMemcpyAsync(object_id, doid.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipMemcpyAsync(prim_id, dpid.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
@@ -777,9 +806,13 @@ int validate_render_desc(const rrt_render_desc* d) {
     if (d->precision > RRT_PRECISION_F64) return fail(RRT_ERR_INVALID, "unknown precision %u", d->precision);
     if (d->accel > RRT_ACCEL_SAH_GPU) return fail(RRT_ERR_INVALID, "unknown accel %u", d->accel);
     if (d->pipeline > RRT_PIPELINE_WAVEFRONT) return fail(RRT_ERR_INVALID, "unknown pipeline %u", d->pipeline);
-    if (d->flags & ~(uint32_t)RRT_RENDER_NEE) return fail(RRT_ERR_INVALID, "unknown render flags 0x%x", d->flags);
+    if (d->flags & ~(uint32_t)(RRT_RENDER_NEE | RRT_RENDER_EXACT_HITS)) return fail(RRT_ERR_INVALID, "unknown render flags 0x%x", d->flags);
     if ((d->flags & RRT_RENDER_NEE) && d->pipeline == RRT_PIPELINE_WAVEFRONT)
         return fail(RRT_ERR_UNSUPPORTED, "next-event estimation runs in the fused pipeline only");
+    if ((d->flags & RRT_RENDER_EXACT_HITS) && d->pipeline == RRT_PIPELINE_WAVEFRONT)
+        return fail(RRT_ERR_UNSUPPORTED, "RRT_RENDER_EXACT_HITS runs in the fused pipeline only");
+    if ((d->flags & RRT_RENDER_EXACT_HITS) && (d->flags & RRT_RENDER_NEE))
+        return fail(RRT_ERR_UNSUPPORTED, "RRT_RENDER_EXACT_HITS and RRT_RENDER_NEE cannot be combined");
     return RRT_OK;
 }
 
@@ -801,7 +834,7 @@ rrt::RenderParams make_render_params(const rrt_render_desc* desc, uint64_t lanes
         while ((1u << rp.x_shift) < rp.x_strata) rp.x_shift++;
     }
     rp.perm_mask = next_pow2_mask(desc->spp);
-    rp.flags = (desc->flags & RRT_RENDER_NEE) ? rrt::RENDER_FLAG_NEE : 0u;
+    rp.flags = ((desc->flags & RRT_RENDER_NEE) ? rrt::RENDER_FLAG_NEE : 0u) | ((desc->flags & RRT_RENDER_EXACT_HITS) ? rrt::RENDER_FLAG_EXACT : 0u);
     rp.min_depth = desc->min_depth;
     rp.max_depth = desc->max_depth;
     rp.sample_begin = (uint32_t)desc->sample_begin;
@@ -1154,7 +1187,7 @@ int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t preci
     if (precision == RRT_PRECISION_F64)
         HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v64, kind), use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
     else
-        HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v32, kind), use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
+        HIP_TRY(rrt::launch_intersect(with_tree(be, ds, ds->v32, kind), with_tree(be, ds, ds->v64, kind), ds->err32, use_bvh, false, n, sp->origins, sp->dirs, sp->object_id, sp->prim_id, sp->t, be->stream));
     HIP_TRY(hipMemcpyAsync(object_id, sp->object_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipMemcpyAsync(prim_id, sp->prim_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipMemcpyAsync(t, sp->t, n * sizeof(double), hipMemcpyDeviceToHost, be->stream));
@@ -1179,8 +1212,8 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     const bool use_bvh = kind >= 0;
     // AUTO: tree traversal wants many waves in flight, which the register-lean closest-hit kernel of
     // the wavefront pipeline has; a scan over a few primitives is fastest with the path in registers
-    const bool nee = (desc->flags & RRT_RENDER_NEE) != 0;
-    if (nee && ds->n_unbounded_lights > 0)
+    const bool nee = (desc->flags & (RRT_RENDER_NEE | RRT_RENDER_EXACT_HITS)) != 0;  // flags that only the fused kernel serves
+    if ((desc->flags & RRT_RENDER_NEE) && ds->n_unbounded_lights > 0)
         return fail(RRT_ERR_UNSUPPORTED, "next-event estimation cannot sample the scene's %d emissive plane(s)", ds->n_unbounded_lights);
     const bool wavefront = desc->pipeline == RRT_PIPELINE_WAVEFRONT ||
                            (desc->pipeline == RRT_PIPELINE_AUTO && !nee && use_bvh && scene->prims.size() > kAutoWavefrontThreshold &&
@@ -1219,7 +1252,7 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         if (desc->precision == RRT_PRECISION_F64)
             HIP_TRY(rrt::launch_render_fused(with_tree(be, ds, ds->v64, kind), ds->l64, use_bvh, rp, n_blocks, be->stream));
         else
-            HIP_TRY(rrt::launch_render_fused(with_tree(be, ds, ds->v32, kind), ds->l32, use_bvh, rp, n_blocks, be->stream));
+            HIP_TRY(rrt::launch_render_fused(with_tree(be, ds, ds->v32, kind), with_tree(be, ds, ds->v64, kind), ds->err32, ds->l32, use_bvh, rp, n_blocks, be->stream));
     }
     HIP_TRY(hipEventRecord(be->ev1, be->stream));
 
@@ -1257,6 +1290,7 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         stats->tree_built = built_now ? 1u : 0u;
         stats->tree_build_ms = built_now ? ds->tree[kind].build_ms : 0.0;
         stats->stack_overflows = counters[rrt::COUNTER_STACK_OVERFLOW];
+        stats->exact_redos = counters[rrt::COUNTER_EXACT_REDOS];
     }
     return RRT_OK;
 }

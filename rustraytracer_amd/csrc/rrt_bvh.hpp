@@ -24,8 +24,13 @@ RRT_DEV void hit_init(HitAcc<R>& h) {
     h.last_incl = -1;
 }
 
-template <typename R>
-RRT_DEV void hit_consider(HitAcc<R>& h, R t, int g, bool inclusive) {
+// (tracked queries: two accepted hits whose distances differ by less than their error bounds are an undecided order)
+template <typename R, bool TRACK = false>
+RRT_DEV void hit_consider(HitAcc<R>& h, R t, int g, bool inclusive, HitTrack<TRACK>* tr = nullptr) {
+    if constexpr (TRACK) {
+        if (h.first >= 0 && !(__builtin_fabsf(t - h.t) > tr->last_err + tr->best_err)) tr->amb = true;
+        if (t < h.t) tr->best_err = tr->last_err;
+    }
     if (t < h.t) {
         h.t = t;
         h.first = g;
@@ -161,8 +166,10 @@ RRT_DEV float byte_to_float(uint32_t word, int k) {  // v_cvt_f32_ubyte<k>
 // four children.  dist[k] = entry distance of child k, or +inf if the ray misses it (or the slot is empty).
 // Conservative: boxes are padded on the host, quantised outward by the builder, and the exit
 // distance is widened by a few ulps, so the only effect of rounding is an extra visit.
+// t_limit: boxes that begin beyond it are skipped (the closest distance so far; a tracked query adds that distance's
+// error bound, so that no box is skipped for a distance that f64 might find larger)
 template <typename R>
-RRT_DEV void node_children(const TreeWalk<R>& w, uint4 q0, uint4 q1, uint4 q2, uint4 q3, R (&dist)[4], int (&child)[4]) {
+RRT_DEV void node_children(const TreeWalk<R>& w, uint4 q0, uint4 q1, uint4 q2, uint4 q3, R (&dist)[4], int (&child)[4], R t_limit) {
     const R widen = sizeof(R) == 4 ? R(1.0000004) : R(1.0000000001);
     const R inf = Num<R>::tmax();
     // plane distance t = (org + q s - o) / d = q (s / d) + (org - o) / d: two multiplies and a subtract per
@@ -193,7 +200,7 @@ RRT_DEV void node_children(const TreeWalk<R>& w, uint4 q0, uint4 q1, uint4 q2, u
         const R en = fmax(fmax((R)tx.x, (R)ty.x), (R)tz.x);
         const R ex = fmin(fmin((R)tx.y, (R)ty.y), (R)tz.y) * widen;
         child[k] = link[k];
-        const bool hit = en <= fmin(ex, w.acc.t) && ex >= R(0) && child[k] != BVH_NO_CHILD;
+        const bool hit = en <= fmin(ex, t_limit) && ex >= R(0) && child[k] != BVH_NO_CHILD;
         dist[k] = hit ? en : inf;
     }
 }
@@ -217,10 +224,10 @@ RRT_DEV void node_descend(TreeWalk<R>& w, R (&dist)[4], int (&child)[4], Push pu
 
 template <typename R>
 RRT_DEV void walk_node(TreeWalk<R>& w, TreeStackLds& lds, TreeStackSpill& spill, uint4 q0, uint4 q1, uint4 q2, uint4 q3,
-                       unsigned long long* overflow) {
+                       unsigned long long* overflow, R t_limit) {
     R dist[4];
     int child[4];
-    node_children(w, q0, q1, q2, q3, dist, child);
+    node_children(w, q0, q1, q2, q3, dist, child, t_limit);
     node_descend(w, dist, child, [&](int c) { walk_push(w, lds, spill, c, overflow); }, [&]() { walk_pop(w, lds, spill); });
 }
 
@@ -262,32 +269,37 @@ RRT_DEV void leaf_test_words(const SceneView<R>& sv, uint4 q0, uint4 q1, uint4 q
 }
 
 // One leaf primitive read through its record (any precision).
-template <typename R>
-RRT_DEV void leaf_test(const SceneView<R>& sv, const LeafRec<R>* leaf, V3<R> o, V3<R> d, HitAcc<R>& acc) {
+template <typename R, bool TRACK = false>
+RRT_DEV void leaf_test(const SceneView<R>& sv, const LeafRec<R>* leaf, V3<R> o, V3<R> d, HitAcc<R>& acc, HitTrack<TRACK>* tr = nullptr) {
     const int type = leaf->type;
     const int g = leaf->g;
     const PrimRec<R> RRT_CONSTANT* as_prim = (const PrimRec<R> RRT_CONSTANT*)(const void*)leaf;
+    const ErrRec RRT_CONSTANT* er = nullptr;
+    if constexpr (TRACK) er = as_constant(tr->err) + g;
     R t;
     bool ok;
     if (type == PRIM_TRIANGLE) {
-        ok = prim_test_as<R, PRIM_TRIANGLE>(as_prim, o, d, Num<R>::tmax(), t);  // reads f[0..11] only
+        ok = prim_test_as<R, PRIM_TRIANGLE, TRACK>(as_prim, o, d, Num<R>::tmax(), t, tr, er);  // reads f[0..11] only
     } else if (type == PRIM_PGRAM) {
-        ok = prim_test_as<R, PRIM_PGRAM>(as_prim, o, d, Num<R>::tmax(), t);     // reads f[0..11] only
+        ok = prim_test_as<R, PRIM_PGRAM, TRACK>(as_prim, o, d, Num<R>::tmax(), t, tr, er);     // reads f[0..11] only
     } else {
-        ok = prim_test(as_constant(sv.prims) + g, o, d, Num<R>::tmax(), t);     // sphere, general quad
+        ok = prim_test<R, TRACK>(as_constant(sv.prims) + g, o, d, Num<R>::tmax(), t, tr, er);   // sphere, general quad
     }
-    if (ok) hit_consider(acc, t, g, type != PRIM_TRIANGLE);
+    if (ok) hit_consider<R, TRACK>(acc, t, g, type != PRIM_TRIANGLE, tr);
 }
 
 // The primitives kept out of the tree (unbounded planes, bent quads), scanned wave-uniformly.
-template <typename R>
-RRT_DEV void scan_beside_tree(const SceneView<R>& sv, V3<R> o, V3<R> d, HitAcc<R>& acc, HitCounters& hc) {
+template <typename R, bool TRACK = false>
+RRT_DEV void scan_beside_tree(const SceneView<R>& sv, V3<R> o, V3<R> d, HitAcc<R>& acc, HitCounters& hc, HitTrack<TRACK>* tr = nullptr) {
     const PrimRec<R> RRT_CONSTANT* prims = as_constant(sv.prims);
     const int32_t RRT_CONSTANT* lin = as_constant(sv.linear_prim);
     for (int k = 0; k < sv.n_linear_prims; ++k) {
         const int g = lin[k];
         R t;
-        if (prim_test(prims + g, o, d, Num<R>::tmax(), t)) hit_consider(acc, t, g, prims[g].type != PRIM_TRIANGLE);
+        const ErrRec RRT_CONSTANT* er = nullptr;
+        if constexpr (TRACK) er = as_constant(tr->err) + g;
+        if (prim_test<R, TRACK>(prims + g, o, d, Num<R>::tmax(), t, tr, er))
+            hit_consider<R, TRACK>(acc, t, g, prims[g].type != PRIM_TRIANGLE, tr);
     }
     hc.prim_tests += (uint32_t)sv.n_linear_prims;
 }
@@ -295,15 +307,15 @@ RRT_DEV void scan_beside_tree(const SceneView<R>& sv, V3<R> o, V3<R> d, HitAcc<R
 // Scene::intersect through the tree (plus a scan of the primitives kept out of it): one ray per
 // lane from start to end (parity kernels and the fused renderer; the wavefront pipeline has a
 // persistent variant of this loop).
-template <typename R>
-RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, HitCounters& hc) {
+template <typename R, bool TRACK = false>
+RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, HitCounters& hc, HitTrack<TRACK>* tr = nullptr) {
     __shared__ TreeStackLds s_stack;
     TreeStackSpill spill;
     TreeWalk<R> w;
     hit_init(w.acc);
-    scan_beside_tree(sv, o, d, w.acc, hc);
+    scan_beside_tree<R, TRACK>(sv, o, d, w.acc, hc, tr);
     if (sv.n_bvh_prims == 1) {
-        leaf_test<R>(sv, sv.leaves, o, d, w.acc);
+        leaf_test<R, TRACK>(sv, sv.leaves, o, d, w.acc, tr);
         hc.prim_tests += 1;
     } else if (sv.n_bvh_prims > 1) {
         walk_start(w, o, d);
@@ -312,13 +324,15 @@ RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, 
             if (w.node >= 0) {
                 uint4 q0, q1, q2, q3;
                 tree_node_words(sv, w.node, top_n, q0, q1, q2, q3);
-                walk_node(w, s_stack, spill, q0, q1, q2, q3, sv.stack_overflow);
+                R t_limit = w.acc.t;
+                if constexpr (TRACK) t_limit += 2.f * tr->best_err;
+                walk_node(w, s_stack, spill, q0, q1, q2, q3, sv.stack_overflow, t_limit);
                 hc.node_tests += 1;
             }
             if (w.node < 0 && w.node != BVH_DONE) {  // (in the same trip as the node step that led here)
                 const int v = ~w.node;
                 const int slot = v & BVH_SLOT_MASK, left = v >> BVH_SLOT_BITS;
-                leaf_test<R>(sv, sv.leaves + slot, w.o, w.d, w.acc);
+                leaf_test<R, TRACK>(sv, sv.leaves + slot, w.o, w.d, w.acc, tr);
                 hc.prim_tests += 1;
                 if (left > 0) w.node = ~((slot + 1) | ((left - 1) << BVH_SLOT_BITS));
                 else walk_pop(w, s_stack, spill);
@@ -330,14 +344,41 @@ RRT_DEV int closest_hit_bvh(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t_out, 
 }
 
 // Closest hit over the whole scene.  Returns the scan-order primitive index or -1.
-template <typename R, bool BVH>
-RRT_DEV int closest_hit(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t, HitCounters& hc) {
-    if (BVH) return closest_hit_bvh<R>(sv, o, d, t, hc);
+template <typename R, bool BVH, bool TRACK = false>
+RRT_DEV int closest_hit(const SceneView<R>& sv, V3<R> o, V3<R> d, R& t, HitCounters& hc, HitTrack<TRACK>* tr = nullptr) {
+    if (BVH) return closest_hit_bvh<R, TRACK>(sv, o, d, t, hc, tr);
     R best_t = Num<R>::tmax();
     int best_g = -1;
-    scan_linear(sv, o, d, best_t, best_g, hc);
+    scan_linear<R, TRACK>(sv, o, d, best_t, best_g, hc, tr);
     t = best_t;
     return best_g;
+}
+
+// The closest hit of the f32 kernels, made to name the primitive the f64 arithmetic names: the f32 query is tracked
+// (HitTrack), and a lane whose query met a decision inside its error bound repeats it in f64 on the f64 tables, with the
+// ray (o64, d64) -- the f64 ray the f32 one was rounded from (e_in = 1), or the f32 ray itself widened (e_in = 0).
+// The f32 distance stands unless f64 names another primitive.  The linear scan reads its tables wave-uniformly, so all
+// lanes of a wave run the f64 scan when one of them needs it; a walk through the tree is per lane.
+// Returns the primitive; `redone` says whether this lane asked for f64.
+template <bool BVH>
+RRT_DEV int closest_hit_exact(const SceneView<float>& sv, const SceneView<double>& sv64, const ErrRec* err, V3<float> o, V3<float> d,
+                              V3<double> o64, V3<double> d64, float e_in, float& t, HitCounters& hc, bool& redone) {
+    HitTrack<true> tr;
+    track_start(tr, err, o, e_in);
+    int g = closest_hit<float, BVH, true>(sv, o, d, t, hc, &tr);
+    redone = tr.amb;
+    if (__ballot(tr.amb) != 0ull) {
+        if (!BVH || tr.amb) {
+            double t64;
+            HitCounters hc64{0, 0};
+            const int g64 = closest_hit<double, BVH>(sv64, o64, d64, t64, hc64);
+            if (tr.amb && g64 != g) {
+                g = g64;
+                t = g64 >= 0 ? (float)t64 : Num<float>::tmax();
+            }
+        }
+    }
+    return g;
 }
 
 }  // namespace rrt

@@ -385,10 +385,94 @@ RRT_DEV void sphere_roots(T cx, T cy, T cz, T r2, V3<R> o, V3<R> d, T& t0, T& x,
     select_lt(ta, Num<R>::tmin(), tb, ta, t0);  // t0 < t_min ? t1 : t0
 }
 
+// ---------------------------------------------------------------- which f32 decisions can be trusted
+// The f32 tests above decide by the sign of a fold of terms (edge coefficients, |n.d| - 1e-6, t - t_min, best_t - t).
+// Evaluated in f64 from the f64 scene and the f64 ray they can come out the other way when the deciding term is
+// smaller than the rounding error it carries.  A tracked query (TRACK = true; f32 only) bounds that error for every
+// primitive it tests, from per-primitive magnitudes prepared by the host (ErrRec) and the ray's own numbers, and
+// raises `amb` when a fold lies inside its bound; the caller then repeats the query in f64 (closest_hit_exact).
+// The bounds are first-order running-error bounds.  With u = 2^-24: n.d carries at most 4 u sum |n_i d_i| (the three
+// entries of n rounded from f64, one product and two fused multiply-adds), k - n.o at most 5 u (|k| + sum |n_i o_i|), the
+// reciprocal 2 u (v_rcp_f32: one ulp) and the product one more; a ray rounded from f64 adds one u to each:
+//   ku    = 1.25 (5 + e_in) u, e_in = error of the ray's components in units of u (0 for a ray that IS f32, 1 for one
+//           rounded from f64); the 1.25 covers the second-order terms and the error of |1 / n.d| itself (see below)
+//   planar primitive (n, k; rows A, B):   M = |k| + sum |n_i| |o_i|,  N1 = sum |n_i|,  A1 = max(sum |A_i|, sum |B_i|)
+//     E_t  = ku (|1 / n.d| (M + N1 |t|) + |t|)                    error of t
+//     E_ab = A1 (E_t + 2 ku (|o|_inf + |t|)) + ku (max(|cA|, |cB|) + 1)   error of a row's coefficient at the hit point
+//     fold trusted iff |fold| > 2 E_ab + E_t + ku N1 + (error of the closest distance so far)
+//   and never when |n.d| <= 16 ku N1 (its reciprocal is not known to 6 %) unless |n.d| - 1e-6 < -ku N1 (parallel for sure).
+// The sphere's terms are bounded the same way, step by step, in sphere_track.
+// (ErrRec: rrt_types.hpp -- planar: N1, |k|, A1, max(|cA|, |cB|) + 1 [, the same four of a general quad's second corner];
+//  sphere: |c|_inf)
+template <bool ON>
+struct HitTrack {};
+template <>
+struct HitTrack<true> {
+    bool amb;        // some decision of this query lies inside its error bound
+    float best_err;  // error bound of the closest distance found so far
+    float last_err;  // error bound of the distance the last primitive test reported
+    float ku;
+    float om;        // |o|_inf of the ray
+    const ErrRec* err;  // the scene's magnitudes, scan order
+};
+RRT_DEV void track_start(HitTrack<true>& tr, const ErrRec* err, V3<float> o, float e_in) {
+    tr.err = err;
+    tr.amb = false;
+    tr.best_err = tr.last_err = 0.f;
+    tr.ku = 1.25f * (5.f + e_in) * 5.9604644775390625e-8f;
+    tr.om = fmaxf(fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+}
+RRT_DEV void track_accept(HitTrack<true>& tr) { tr.best_err = tr.last_err; }
+RRT_DEV void track_accept(HitTrack<false>&) {}
+
+// E_t and E_ab of one plane (n = f[0..2], k = f[3]) with magnitudes e[0..3]
+RRT_DEV void plane_track(const HitTrack<true>& tr, float n0, float n1, float n2, const float RRT_CONSTANT* e, V3<float> o,
+                         float rc, float t, float& et, float& eab) {
+    const float at = __builtin_fabsf(t), arc = __builtin_fabsf(rc);
+    const float m = __builtin_fmaf(__builtin_fabsf(n2), __builtin_fabsf(o.z),
+                                   __builtin_fmaf(__builtin_fabsf(n1), __builtin_fabsf(o.y), __builtin_fmaf(__builtin_fabsf(n0), __builtin_fabsf(o.x), e[1])));
+    et = tr.ku * __builtin_fmaf(arc, __builtin_fmaf(e[0], at, m), at);
+    eab = __builtin_fmaf(e[2], __builtin_fmaf(2.f * tr.ku, tr.om + at, et), tr.ku * e[3]);
+}
+
+// Judges a planar test: fold = the number whose sign decided, nd = n.d, det_ok = |n.d| - 1e-6, bound = its error.
+RRT_DEV void track_judge(HitTrack<true>& tr, float fold, float nd, float det_ok, float n1sum, float bound) {
+    const float e_nd = tr.ku * n1sum;
+    if (det_ok < -e_nd) return;  // parallel beyond doubt: rejected in any arithmetic
+    const bool trusted = (__builtin_fabsf(nd) > 16.f * e_nd) && (__builtin_fabsf(fold) > bound + tr.best_err);
+    if (!trusted) tr.amb = true;
+}
+
+// The sphere test's decisions (sphere_roots + the range tests): x = r^2 - d2 >= 0, ta < t_min (which root),
+// t0 - t_min >= 0, best_t - t0 >= 0.
+RRT_DEV void sphere_track(HitTrack<true>& tr, const float RRT_CONSTANT* f, const float RRT_CONSTANT* e, V3<float> o, V3<float> d,
+                          float x, float d2, float t0, float best_t) {
+#pragma clang fp contract(off)
+    const float ku = tr.ku;
+    const float lx = f[0] - o.x, ly = f[1] - o.y, lz = f[2] - o.z;
+    const float l1 = __builtin_fabsf(lx) + __builtin_fabsf(ly) + __builtin_fabsf(lz);
+    const float t_ca = lz * d.z + (ly * d.y + lx * d.x);
+    const float el = ku * (e[0] + tr.om);                  // error of a component of l = c - o
+    const float e_tca = 3.f * el + ku * l1;
+    const float e_q = el + e_tca + ku * (l1 + __builtin_fabsf(t_ca));  // of a component of q = l - t_ca d
+    const float q1 = 1.7320508f * __builtin_amdgcn_sqrtf(d2);           // >= |q|_1
+    const float e_x = 2.f * q1 * e_q + ku * (d2 + f[4]);
+    if (x < -e_x) { tr.last_err = 0.f; return; }           // misses beyond doubt
+    if (!(x > e_x)) { tr.amb = true; return; }
+    const float t_hc = __builtin_amdgcn_sqrtf(x);
+    const float e_t0 = e_tca + e_x * __builtin_amdgcn_rcpf(t_hc) + ku * (__builtin_fabsf(t_ca) + t_hc);
+    tr.last_err = e_t0;
+    const float ta = t_ca - t_hc;
+    const float fold = fminf(t0 - Num<float>::tmin(), best_t - t0);
+    if (!(__builtin_fabsf(ta - Num<float>::tmin()) > e_t0) || !(__builtin_fabsf(fold) > e_t0 + tr.best_err)) tr.amb = true;
+}
+
 // TYPE is a compile-time constant in the run loops of the linear scan (no per-primitive
 // dispatch) and a per-lane value in tree leaves.
-template <typename R, int TYPE>
-RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
+template <typename R, int TYPE, bool TRACK = false>
+RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out,
+                          HitTrack<TRACK>* tr = nullptr, const ErrRec RRT_CONSTANT* er = nullptr) {
+    static_assert(!TRACK || sizeof(R) == 4, "only the f32 tests are tracked");
     const R RRT_CONSTANT* f = p->f;
     if (TYPE >= PRIM_TRIANGLE) {
 #pragma clang fp contract(off)
@@ -401,11 +485,18 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
         R a = plane_coeff<R>(f[4], f[5], f[6], f[7], px, py, pz);
         R b = plane_coeff<R>(f[8], f[9], f[10], f[11], px, py, pz);
         R det_ok = Num<R>::abs(nd) - Num<R>::eps();
+        float et = 0.f, eab = 0.f;
+        if constexpr (TRACK) {
+            plane_track(*tr, f[0], f[1], f[2], er->e, o, Num<R>::rcp(nd), t, et, eab);
+            tr->last_err = et;
+        }
         if (TYPE == PRIM_PGRAM) {
             // parallelogram: alpha' = 1 - alpha and beta' = 1 - beta, so the two-triangle
             // test is 0 <= alpha, beta <= 1; a and b arrive shifted by -1/2
             R h = min3(R(0.5) - Num<R>::abs(a), R(0.5) - Num<R>::abs(b), det_ok);
-            return min3(h, t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
+            const R fold = min3(h, t - Num<R>::tmin(), headroom(best_t, t));
+            if constexpr (TRACK) track_judge(*tr, fold, nd, det_ok, er->e[0], 2.f * eab + et + tr->ku * er->e[0]);
+            return fold >= R(0);
         }
         if (TYPE == PRIM_QUAD) {
             // The corner at v2 (src/shapes/quadrilateral.rs:90-111): the reference intersects the ray with the
@@ -423,16 +514,29 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
             R second = min3(a2, b2, Num<R>::abs(nd2) - Num<R>::eps());  // the (v2, v3, v1) corner
             R inside = fmax(R(1) - (a + b), second);                      // alpha + beta <= 1, or that corner
             R h = min3(min3(a, b, inside), det_ok, t - Num<R>::tmin());
-            return fmin(h, headroom(best_t, t)) >= R(0);
+            const R fold = fmin(h, headroom(best_t, t));
+            if constexpr (TRACK) {
+                // the second corner's terms carry the error of their own plane; that plane being (nearly) parallel
+                // to the ray makes them untrustworthy, not the test (its first corner may still decide)
+                float et2, eab2;
+                plane_track(*tr, f[20], f[21], f[22], er->e + 4, o, Num<R>::rcp(nd2), t2, et2, eab2);
+                float bound = 2.f * eab + et + tr->ku * er->e[0] + 2.f * eab2 + tr->ku * er->e[4];
+                if (!(__builtin_fabsf(nd2) > 16.f * tr->ku * er->e[4])) bound = 3.0e38f;
+                track_judge(*tr, fold, nd, det_ok, er->e[0], bound);
+            }
+            return fold >= R(0);
         }
         // triangle: u, v >= 0, u <= 1, u + v <= 1, and an OPEN t interval
         R h = min3(min3(a, b, R(1) - a), R(1) - (a + b), det_ok);
-        return (h >= R(0)) && (fmin(t - Num<R>::tmin(), headroom(best_t, t)) > R(0));
+        const R h2 = fmin(t - Num<R>::tmin(), headroom(best_t, t));
+        if constexpr (TRACK) track_judge(*tr, fmin(h, h2), nd, det_ok, er->e[0], 2.f * eab + et + tr->ku * er->e[0]);
+        return (h >= R(0)) && (h2 > R(0));
     }
     if (TYPE == PRIM_SPHERE) {  // src/shapes/sphere.rs:58-96
         R t0, x, d2;
         sphere_roots<R, R>(f[0], f[1], f[2], f[4], o, d, t0, x, d2);
         t_out = t0;
+        if constexpr (TRACK) sphere_track(*tr, f, er->e, o, d, x, d2, t0, best_t);
         return min3(fmin(x, d2), t0 - Num<R>::tmin(), headroom(best_t, t0)) >= R(0);
     }
     // plane, src/shapes/plane.rs:25-44
@@ -442,18 +546,27 @@ RRT_DEV bool prim_test_as(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R 
         plane_nd_no<R, R>(f[0], f[1], f[2], f[3], o, d, nd, no);
         R t = no * Num<R>::rcp(nd);
         t_out = t;
-        return min3(Num<R>::abs(nd) - Num<R>::eps(), t - Num<R>::tmin(), headroom(best_t, t)) >= R(0);
+        const R det_ok = Num<R>::abs(nd) - Num<R>::eps();
+        const R fold = min3(det_ok, t - Num<R>::tmin(), headroom(best_t, t));
+        if constexpr (TRACK) {
+            float et, eab;
+            plane_track(*tr, f[0], f[1], f[2], er->e, o, Num<R>::rcp(nd), t, et, eab);
+            tr->last_err = et;
+            track_judge(*tr, fold, nd, det_ok, er->e[0], et + tr->ku * er->e[0]);
+        }
+        return fold >= R(0);
     }
 }
 
-template <typename R>
-RRT_DEV bool prim_test(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out) {
+template <typename R, bool TRACK = false>
+RRT_DEV bool prim_test(const PrimRec<R> RRT_CONSTANT* p, V3<R> o, V3<R> d, R best_t, R& t_out,
+                       HitTrack<TRACK>* tr = nullptr, const ErrRec RRT_CONSTANT* er = nullptr) {
     switch (p->type) {
-    case PRIM_SPHERE: return prim_test_as<R, PRIM_SPHERE>(p, o, d, best_t, t_out);
-    case PRIM_PLANE: return prim_test_as<R, PRIM_PLANE>(p, o, d, best_t, t_out);
-    case PRIM_TRIANGLE: return prim_test_as<R, PRIM_TRIANGLE>(p, o, d, best_t, t_out);
-    case PRIM_QUAD: return prim_test_as<R, PRIM_QUAD>(p, o, d, best_t, t_out);
-    default: return prim_test_as<R, PRIM_PGRAM>(p, o, d, best_t, t_out);
+    case PRIM_SPHERE: return prim_test_as<R, PRIM_SPHERE, TRACK>(p, o, d, best_t, t_out, tr, er);
+    case PRIM_PLANE: return prim_test_as<R, PRIM_PLANE, TRACK>(p, o, d, best_t, t_out, tr, er);
+    case PRIM_TRIANGLE: return prim_test_as<R, PRIM_TRIANGLE, TRACK>(p, o, d, best_t, t_out, tr, er);
+    case PRIM_QUAD: return prim_test_as<R, PRIM_QUAD, TRACK>(p, o, d, best_t, t_out, tr, er);
+    default: return prim_test_as<R, PRIM_PGRAM, TRACK>(p, o, d, best_t, t_out, tr, er);
     }
 }
 
@@ -462,15 +575,16 @@ struct HitCounters {
     uint32_t node_tests;
 };
 
-template <typename R, int TYPE>
+template <typename R, int TYPE, bool TRACK = false>
 RRT_DEV void scan_run(const PrimRec<R> RRT_CONSTANT* prims, int first, int count, V3<R> o, V3<R> d,
-                      R& best_t, int& best_g) {
+                      R& best_t, int& best_g, HitTrack<TRACK>* tr = nullptr, const ErrRec RRT_CONSTANT* err = nullptr) {
 #pragma unroll 2
     for (int k = 0; k < count; ++k) {
         R t;
-        const bool ok = prim_test_as<R, TYPE>(prims + first + k, o, d, best_t, t);
+        const bool ok = prim_test_as<R, TYPE, TRACK>(prims + first + k, o, d, best_t, t, tr, TRACK ? err + first + k : nullptr);
         best_t = ok ? t : best_t;
         best_g = ok ? first + k : best_g;
+        if constexpr (TRACK) { if (ok) track_accept(*tr); }
     }
 }
 
@@ -571,12 +685,28 @@ RRT_DEV void scan_run_pairs_round(const PairRec<R> RRT_CONSTANT* pairs, int firs
 // the reference's order with a shrinking t_max.  The table index is uniform
 // across the wave, so records arrive through scalar loads.  The table is cut
 // into runs of equal type (host side), each run is a tight loop of one test.
-template <typename R>
+template <typename R, bool TRACK = false>
 RRT_DEV void scan_linear(const SceneView<R>& sv, V3<R> o, V3<R> d, R& best_t, int& best_g,
-                         HitCounters& hc) {
+                         HitCounters& hc, HitTrack<TRACK>* tr = nullptr) {
     const PrimRec<R> RRT_CONSTANT* prims = as_constant(sv.prims);
     const int32_t RRT_CONSTANT* runs = as_constant(sv.runs);
     const int n_runs = sv.n_runs;
+    if constexpr (TRACK) {
+        // a tracked scan tests every primitive through prim_test_as, whose arithmetic the pair scans repeat operation
+        // by operation: same distances, same verdicts, plus the error bounds
+        const ErrRec RRT_CONSTANT* err = as_constant(tr->err);
+        for (int r = 0; r < n_runs; ++r) {
+            const int type = runs[4 * r], first = runs[4 * r + 1], count = runs[4 * r + 2];
+            switch (type) {
+            case PRIM_SPHERE: scan_run<R, PRIM_SPHERE, true>(prims, first, count, o, d, best_t, best_g, tr, err); break;
+            case PRIM_PLANE: scan_run<R, PRIM_PLANE, true>(prims, first, count, o, d, best_t, best_g, tr, err); break;
+            case PRIM_TRIANGLE: scan_run<R, PRIM_TRIANGLE, true>(prims, first, count, o, d, best_t, best_g, tr, err); break;
+            case PRIM_QUAD: scan_run<R, PRIM_QUAD, true>(prims, first, count, o, d, best_t, best_g, tr, err); break;
+            default: scan_run<R, PRIM_PGRAM, true>(prims, first, count, o, d, best_t, best_g, tr, err); break;
+            }
+        }
+        return;
+    }
     for (int r = 0; r < n_runs; ++r) {
         const int type = runs[4 * r], first = runs[4 * r + 1], count = runs[4 * r + 2];
         switch (type) {

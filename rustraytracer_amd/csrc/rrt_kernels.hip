@@ -19,25 +19,35 @@
 namespace rrt {
 
 // ------------------------------------------------------------------ parity kernels
+// R = double: the query in f64.  R = float: the f32 query of the product kernels, tracked, with the rays it could not
+// decide within f32's error bounds repeated in f64 from the caller's f64 ray (closest_hit_exact): the primitive is the
+// one the f64 query names, the distance the f32 one unless the primitive changed.
 template <typename R, bool BVH, bool PRIMARY>
 __global__ void __launch_bounds__(256)
-intersect_kernel(SceneView<R> sv, size_t n, const double* __restrict__ a, const double* __restrict__ b,
+intersect_kernel(SceneView<R> sv, SceneView<double> sv64, const ErrRec* err, size_t n, const double* __restrict__ a, const double* __restrict__ b,
                  int32_t* __restrict__ object_id, int32_t* __restrict__ prim_id, double* __restrict__ t_out) {
     // every lane of a wave runs the scan (wave-uniform loads, wave votes); lanes past n are masked at the store
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t j = i < n ? i : n - 1;
-    V3<R> o, d;
+    V3<double> o64, d64;
     if (PRIMARY) {
-        o = mk<R>(sv.cam_o[0], sv.cam_o[1], sv.cam_o[2]);
-        d = camera_dir<R>(sv, (R)a[j], (R)b[j]);
+        o64 = mk<double>(sv64.cam_o[0], sv64.cam_o[1], sv64.cam_o[2]);
+        d64 = camera_dir<double>(sv64, a[j], b[j]);
     } else {
-        o = mk<R>((R)a[3 * j], (R)a[3 * j + 1], (R)a[3 * j + 2]);
-        d = mk<R>((R)b[3 * j], (R)b[3 * j + 1], (R)b[3 * j + 2]);
+        o64 = mk<double>(a[3 * j], a[3 * j + 1], a[3 * j + 2]);
+        d64 = mk<double>(b[3 * j], b[3 * j + 1], b[3 * j + 2]);
     }
     HitCounters hc{0, 0};
     R t;
     if (BVH) tree_top_load(sv);
-    int g = closest_hit<R, BVH>(sv, o, d, t, hc);
+    int g;
+    if constexpr (sizeof(R) == 4) {
+        bool redone;
+        g = closest_hit_exact<BVH>(sv, sv64, err, mk<float>((float)o64.x, (float)o64.y, (float)o64.z),
+                                   mk<float>((float)d64.x, (float)d64.y, (float)d64.z), o64, d64, 1.f, t, hc, redone);
+    } else {
+        g = closest_hit<R, BVH>(sv, o64, d64, t, hc);
+    }
     if (i < n) {
         if (g >= 0) {
             object_id[i] = sv.shade[g].object_id;
@@ -83,9 +93,11 @@ constexpr int FUSED_LDS_PRIMS = 64;
 #else
 #define RRT_FUSED_OCCUPANCY
 #endif
-template <typename R, bool BVH, bool LDS_TABLES, bool NEE = false>
+// EXACT (RRT_RENDER_EXACT_HITS, f32 only): every closest-hit query is tracked and repeated in f64 where f32 cannot
+// decide it (closest_hit_exact, with the f32 ray widened); a separate instantiation like NEE.
+template <typename R, bool BVH, bool LDS_TABLES, bool NEE = false, bool EXACT = false>
 __global__ void __launch_bounds__(256) RRT_FUSED_OCCUPANCY
-render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
+render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights, SceneView<double> sv64, const ErrRec* err) {
     __shared__ ShadeRec<R> s_shade[LDS_TABLES ? FUSED_LDS_PRIMS : 1];
     __shared__ MatRec<R> s_mats[LDS_TABLES ? FUSED_LDS_PRIMS : 1];
     if (LDS_TABLES) {
@@ -119,7 +131,7 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
 
     // wave-uniform event counters: bumped by ballots taken outside the divergent
     // regions, so they stay in scalar registers
-    uint32_t c_rays = 0, c_nonfinite = 0, c_samples = 0;
+    uint32_t c_rays = 0, c_nonfinite = 0, c_samples = 0, c_redos = 0;
     uint32_t shadow_rays = 0;       // per lane (NEE only)
     bool lights_sampled = false;    // NEE: the path's previous vertex sampled the lights, so an emitter found now adds nothing
     HitCounters hc{0, 0};
@@ -138,7 +150,15 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
             int g = (int)(path.smp.key % (uint32_t)sv.n_prims);
             t = R(0.3);
 #else
-            int g = closest_hit<R, BVH>(sv, path.o, path.d, t, hc);
+            int g;
+            if constexpr (EXACT && sizeof(R) == 4) {
+                bool redone;
+                g = closest_hit_exact<BVH>(sv, sv64, err, path.o, path.d, mk<double>(path.o.x, path.o.y, path.o.z),
+                                           mk<double>(path.d.x, path.d.y, path.d.z), 0.f, t, hc, redone);
+                c_redos += redone ? 1u : 0u;
+            } else {
+                g = closest_hit<R, BVH>(sv, path.o, path.d, t, hc);
+            }
 #endif
 #ifdef RRT_EXP_NOSHADE
             acc.x += t; acc.y += (R)g;
@@ -297,6 +317,9 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
         for (int off = 32; off > 0; off >>= 1) shadow_rays += __shfl_xor(shadow_rays, off);
         c_rays += shadow_rays;
     }
+    if (EXACT) {
+        for (int off = 32; off > 0; off >>= 1) c_redos += __shfl_xor(c_redos, off);
+    }
     if (!BVH) {
         hc.prim_tests = c_rays * (uint32_t)sv.n_prims;  // a linear scan tests every primitive
     } else {
@@ -319,6 +342,7 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights) {
             atomicAdd(&counters[COUNTER_BOUNCE0 + k], (unsigned long long)bc.bounce[k]);
         atomicAdd(&counters[COUNTER_NONFINITE], (unsigned long long)c_nonfinite);
         atomicAdd(&counters[COUNTER_SAMPLES], (unsigned long long)c_samples);
+        if (EXACT) atomicAdd(&counters[COUNTER_EXACT_REDOS], (unsigned long long)c_redos);
     }
 }
 
@@ -388,60 +412,69 @@ postprocess_kernel(const float* __restrict__ sum, double inv_spp, PostParams pp,
 
 // ------------------------------------------------------------------ launchers
 template <typename R>
-static hipError_t launch_intersect_t(const SceneView<R>& sv, bool bvh, bool primary, size_t n, const double* a,
+static hipError_t launch_intersect_t(const SceneView<R>& sv, const SceneView<double>& sv64, const ErrRec* err, bool bvh, bool primary, size_t n, const double* a,
                                      const double* b, int32_t* oid, int32_t* pid, double* t,
                                      hipStream_t stream) {
     if (n == 0) return hipSuccess;
     dim3 block(256), grid((unsigned)((n + 255) / 256));
     if (bvh) {
         if (primary)
-            hipLaunchKernelGGL((intersect_kernel<R, true, true>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+            hipLaunchKernelGGL((intersect_kernel<R, true, true>), grid, block, 0, stream, sv, sv64, err, n, a, b, oid, pid, t);
         else
-            hipLaunchKernelGGL((intersect_kernel<R, true, false>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+            hipLaunchKernelGGL((intersect_kernel<R, true, false>), grid, block, 0, stream, sv, sv64, err, n, a, b, oid, pid, t);
     } else {
         if (primary)
-            hipLaunchKernelGGL((intersect_kernel<R, false, true>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+            hipLaunchKernelGGL((intersect_kernel<R, false, true>), grid, block, 0, stream, sv, sv64, err, n, a, b, oid, pid, t);
         else
-            hipLaunchKernelGGL((intersect_kernel<R, false, false>), grid, block, 0, stream, sv, n, a, b, oid, pid, t);
+            hipLaunchKernelGGL((intersect_kernel<R, false, false>), grid, block, 0, stream, sv, sv64, err, n, a, b, oid, pid, t);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_intersect(const SceneView<float>& sv, bool bvh, bool primary, size_t n, const double* a,
+hipError_t launch_intersect(const SceneView<float>& sv, const SceneView<double>& sv64, const ErrRec* err, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s) {
-    return launch_intersect_t<float>(sv, bvh, primary, n, a, b, oid, pid, t, s);
+    return launch_intersect_t<float>(sv, sv64, err, bvh, primary, n, a, b, oid, pid, t, s);
 }
 hipError_t launch_intersect(const SceneView<double>& sv, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s) {
-    return launch_intersect_t<double>(sv, bvh, primary, n, a, b, oid, pid, t, s);
+    return launch_intersect_t<double>(sv, sv, nullptr, bvh, primary, n, a, b, oid, pid, t, s);
 }
 
 template <typename R>
-static hipError_t launch_render_fused_t(const SceneView<R>& sv, const LightView<R>& lv, bool bvh, const RenderParams& rp, int n_blocks,
+static hipError_t launch_render_fused_t(const SceneView<R>& sv, const SceneView<double>& sv64, const ErrRec* err, const LightView<R>& lv, bool bvh, const RenderParams& rp, int n_blocks,
                                         hipStream_t stream) {
     // RRT_DEBUG_LDS_BYTES: occupancy experiments only (unused dynamic LDS caps the blocks per CU)
     static const size_t lds = [] { const char* e = getenv("RRT_DEBUG_LDS_BYTES"); return e ? (size_t)atol(e) : (size_t)0; }();
     const bool tables = sv.n_prims <= FUSED_LDS_PRIMS && sv.n_objects <= FUSED_LDS_PRIMS;
     if (rp.flags & RENDER_FLAG_NEE) {
         if (bvh)
-            hipLaunchKernelGGL((render_fused<R, true, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
+            hipLaunchKernelGGL((render_fused<R, true, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv, sv64, err);
         else
-            hipLaunchKernelGGL((render_fused<R, false, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
+            hipLaunchKernelGGL((render_fused<R, false, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv, sv64, err);
+        return hipGetLastError();
+    }
+    if constexpr (sizeof(R) == 4) if (rp.flags & RENDER_FLAG_EXACT) {
+        if (bvh)
+            hipLaunchKernelGGL((render_fused<R, true, false, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv, sv64, err);
+        else if (tables)
+            hipLaunchKernelGGL((render_fused<R, false, true, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv, sv64, err);
+        else
+            hipLaunchKernelGGL((render_fused<R, false, false, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv, sv64, err);
         return hipGetLastError();
     }
     if (bvh)
-        hipLaunchKernelGGL((render_fused<R, true, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
+        hipLaunchKernelGGL((render_fused<R, true, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv, sv64, err);
     else if (tables)
-        hipLaunchKernelGGL((render_fused<R, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
+        hipLaunchKernelGGL((render_fused<R, false, true>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv, sv64, err);
     else
-        hipLaunchKernelGGL((render_fused<R, false, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv);
+        hipLaunchKernelGGL((render_fused<R, false, false>), dim3(n_blocks), dim3(256), lds, stream, sv, rp, lv, sv64, err);
     return hipGetLastError();
 }
-hipError_t launch_render_fused(const SceneView<float>& sv, const LightView<float>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
-    return launch_render_fused_t<float>(sv, lv, bvh, rp, n_blocks, s);
+hipError_t launch_render_fused(const SceneView<float>& sv, const SceneView<double>& sv64, const ErrRec* err, const LightView<float>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
+    return launch_render_fused_t<float>(sv, sv64, err, lv, bvh, rp, n_blocks, s);
 }
 hipError_t launch_render_fused(const SceneView<double>& sv, const LightView<double>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s) {
-    return launch_render_fused_t<double>(sv, lv, bvh, rp, n_blocks, s);
+    return launch_render_fused_t<double>(sv, sv, nullptr, lv, bvh, rp, n_blocks, s);
 }
 
 template <typename R>

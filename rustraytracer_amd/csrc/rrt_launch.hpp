@@ -15,12 +15,13 @@ struct PostParams {
 };
 
 // a, b: PRIMARY ? (u[n], v[n]) : (origins[3n], dirs[3n]); all pointers are device memory
-hipError_t launch_intersect(const SceneView<float>& sv, bool bvh, bool primary, size_t n, const double* a,
+// (the f32 query repeats in f64, on sv64, the rays it cannot decide within f32's error bounds: closest_hit_exact)
+hipError_t launch_intersect(const SceneView<float>& sv, const SceneView<double>& sv64, const ErrRec* err, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s);
 hipError_t launch_intersect(const SceneView<double>& sv, bool bvh, bool primary, size_t n, const double* a,
                             const double* b, int32_t* oid, int32_t* pid, double* t, hipStream_t s);
 
-hipError_t launch_render_fused(const SceneView<float>& sv, const LightView<float>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
+hipError_t launch_render_fused(const SceneView<float>& sv, const SceneView<double>& sv64, const ErrRec* err, const LightView<float>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
 hipError_t launch_render_fused(const SceneView<double>& sv, const LightView<double>& lv, bool bvh, const RenderParams& rp, int n_blocks, hipStream_t s);
 
 hipError_t launch_sampler_values(const RenderParams& rp, uint32_t pixel, float* out, hipStream_t stream);

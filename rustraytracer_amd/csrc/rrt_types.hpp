@@ -8,6 +8,11 @@
 
 namespace rrt {
 
+// Magnitudes of one primitive's record for the error bounds of a tracked f32 closest-hit query (rrt_device.hpp, HitTrack).
+struct ErrRec {
+    float e[8];
+};
+
 enum : int {
     PRIM_SPHERE = 0, PRIM_PLANE = 1, PRIM_TRIANGLE = 2, PRIM_QUAD = 3,
     PRIM_PGRAM = 4  // device-only: a quad whose corners form a parallelogram (PrimRec.type only)
@@ -214,7 +219,7 @@ struct RenderParams {
     unsigned long long* work_counter;
 };
 
-enum : uint32_t { RENDER_FLAG_NEE = 1u };
+enum : uint32_t { RENDER_FLAG_NEE = 1u, RENDER_FLAG_EXACT = 2u };
 
 enum : int {
     COUNTER_RAYS = 0,

@@ -250,7 +250,7 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
 #endif
                 R dist[4];
                 int child[4];
-                node_children(w, q0, q1, q2, q3, dist, child);
+                node_children(w, q0, q1, q2, q3, dist, child, w.acc.t);
                 // (a node pushes at most three entries: with room for three in LDS no push needs the spill test)
                 if (w.sp <= WF_STACK_LEVELS - 3)
                     node_descend(w, dist, child, [&](int c) { s_stack[w.sp][threadIdx.x] = c; w.sp += 1; }, pop);

@@ -119,7 +119,7 @@ def test_lbvh_large_mesh_primary_parity(gpu, O):
     assert (ref[0] == 0).sum() > 500  # the mesh fills a good part of the view
     got32 = be.trace_primary(sc, u, v, precision=api.PRECISION_F32)
     bad = (got32[0] != ref[0]) | (got32[1] != ref[1])
-    assert bad.sum() <= 6  # rays through a shared edge of two facets within f32 resolution
+    assert bad.sum() == 0  # rays through a shared edge of two facets within f32 resolution are decided in f64
     ok = ~bad & hit
     assert np.max(np.abs(got32[2][ok] - ref[2][ok]) / ref[2][ok]) <= 1e-5
     lin = be.trace_primary(sc, u, v, precision=api.PRECISION_F32, accel=api.ACCEL_LINEAR)

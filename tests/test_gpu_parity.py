@@ -1,10 +1,10 @@
 """GPU closest-hit vs the f64 oracle, through the C ABI.
 
 Gates (from the backend's charter): for a fixed primary-ray set the hit object / primitive ids match
-the reference's linear scan exactly and hit distances agree within 1e-5 relative.  The f64 kernels must
-meet the id gate with no exception; the f32 kernels may differ only on rays that graze a primitive
-edge within f32 resolution, which the fixed golden set does not contain for the Cornell box and may
-contain at most twice for smallpt (silhouettes of its spheres)."""
+the reference's linear scan exactly and hit distances agree within 1e-5 relative.  Both precisions must
+meet the id gate with no exception: the f32 query bounds the rounding error of every decision it takes and
+repeats in f64, from the caller's f64 ray, the rays whose decisions lie inside those bounds (silhouettes,
+edges, grazing self-hits), so its ids are the f64 query's ids; its distances stay f32."""
 import numpy as np
 import pytest
 
@@ -43,7 +43,7 @@ def test_golden_primary_hits_f64(gpu, scenes, golden_hits, name):
     _compare(got, ref, id_slack=0, t_tol=1e-11)
 
 
-@pytest.mark.parametrize("name,slack", [("cornell_box", 0), ("smallpt", 2)])
+@pytest.mark.parametrize("name,slack", [("cornell_box", 0), ("smallpt", 0)])
 def test_golden_primary_hits_f32(gpu, scenes, golden_hits, name, slack):
     api, be = gpu
     sc = api.Scene(scenes[name])
@@ -63,10 +63,10 @@ def test_large_random_primary_set(gpu, O, scenes, name):
     _compare(be.trace_primary(sc, u, v, precision=api.PRECISION_F64), ref, id_slack=0, t_tol=1e-10)
     got = be.trace_primary(sc, u, v, precision=api.PRECISION_F32)
     bad = (got[0] != ref[0]) | (got[1] != ref[1])
-    assert bad.mean() <= 5e-5  # f32 edge grazes only
-    ok = ~bad & (ref[0] >= 0)
+    assert bad.sum() == 0  # f32: the same ids as f64, ray for ray
+    ok = ref[0] >= 0
     rel = np.abs(got[2][ok] - ref[2][ok]) / ref[2][ok]
-    assert np.quantile(rel, 0.9999) <= T_REL_TOL
+    assert rel.max() <= T_REL_TOL
 
 
 @pytest.mark.parametrize("name", ["cornell_box", "smallpt", "all_prims"])
@@ -81,13 +81,16 @@ def test_secondary_rays(gpu, O, scenes, name):
     # box bottom, which lies in the floor plane: those are exact ties between two primitives
     ties = _compare(be.intersect(sc, o, d, precision=api.PRECISION_F64), ref, id_slack=0, t_tol=1e-9, tie_tol=1e-12)
     assert ties <= 0.005 * len(o)
+    got64 = be.intersect(sc, o, d, precision=api.PRECISION_F64)
     got = be.intersect(sc, o, d, precision=api.PRECISION_F32)
+    # an f32 ray origin sits up to ~1e-7 * scale off the surface it starts on, so in plain f32 a few rays that leave a
+    # surface at a grazing angle see that surface again beyond t_min; the f32 query knows that it cannot tell and asks
+    # f64: its ids are the f64 query's on every ray, the exact ties between two coincident surfaces included
+    assert np.array_equal(got[0], got64[0]) and np.array_equal(got[1], got64[1])
     bad = (got[0] != ref[0]) | (got[1] != ref[1])
     with np.errstate(invalid="ignore", divide="ignore"):
         tie = bad & (np.abs(got[2] - ref[2]) <= 1e-5 * np.abs(ref[2]))
-    # an f32 ray origin sits up to ~1e-7 * scale off the surface it starts on, so a few rays that leave a
-    # surface at a grazing angle see that surface again beyond t_min; everything else must agree
-    assert (bad & ~tie).mean() <= 2e-3
+    assert (bad & ~tie).sum() == 0
 
 
 def test_tie_rule_on_device(gpu):
