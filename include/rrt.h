@@ -92,7 +92,8 @@ typedef enum rrt_pipeline { RRT_PIPELINE_AUTO = 0, RRT_PIPELINE_FUSED = 1, RRT_P
  * on an emissive primitive is sampled (lights chosen in proportion to area x emission, points uniform in area)
  * and connected through a shadow ray; emission found by a scattered ray then counts only after a mirror or
  * dielectric bounce or for the camera ray itself, so every light path is still counted once.  Same expected
- * image, less noise with small lights.  Fused pipeline only; emissive planes (infinite area) are refused.
+ * image, less noise with small lights.  Both pipelines (the wavefront pipeline queues the shadow rays of a trip for a
+ * closest-hit launch of their own); emissive planes (infinite area) are refused.
  * RRT_RENDER_EXACT_HITS: the f32 renderer tracks the rounding-error bound of every closest-hit decision (edge
  * coefficients, |n.d| - 1e-6, t - t_min, the order of two distances) and repeats in f64 the queries in which a decision
  * lies inside its bound, so that every ray it traces meets the primitive the f64 arithmetic of the reference

@@ -237,6 +237,7 @@ struct rrt_backend {
     // wavefront pipeline: queues and control block, allocated on first use and kept
     void* wf_mem = nullptr;
     uint32_t wf_capacity = 0;
+    bool wf_has_shadow = false;  // the shadow-ray queue of next-event estimation is part of wf_mem
     rrt::WfParams wf{};
 };
 
@@ -807,8 +808,6 @@ int validate_render_desc(const rrt_render_desc* d) {
     if (d->accel > RRT_ACCEL_SAH_GPU) return fail(RRT_ERR_INVALID, "unknown accel %u", d->accel);
     if (d->pipeline > RRT_PIPELINE_WAVEFRONT) return fail(RRT_ERR_INVALID, "unknown pipeline %u", d->pipeline);
     if (d->flags & ~(uint32_t)(RRT_RENDER_NEE | RRT_RENDER_EXACT_HITS)) return fail(RRT_ERR_INVALID, "unknown render flags 0x%x", d->flags);
-    if ((d->flags & RRT_RENDER_NEE) && d->pipeline == RRT_PIPELINE_WAVEFRONT)
-        return fail(RRT_ERR_UNSUPPORTED, "next-event estimation runs in the fused pipeline only");
     if ((d->flags & RRT_RENDER_EXACT_HITS) && d->pipeline == RRT_PIPELINE_WAVEFRONT)
         return fail(RRT_ERR_UNSUPPORTED, "RRT_RENDER_EXACT_HITS runs in the fused pipeline only");
     if ((d->flags & RRT_RENDER_EXACT_HITS) && (d->flags & RRT_RENDER_NEE))
@@ -904,25 +903,27 @@ const uint32_t kWfCapacityLinear = 1u << 24;
 const uint32_t kWfCapacityTree = 1u << 27;
 const uint32_t kWfCapacityFloor = 1u << 20;
 
-size_t wavefront_bytes(size_t n) {
+size_t wavefront_bytes(size_t n, bool shadow) {
     const size_t per_queue = n * (sizeof(float4) + sizeof(float2) + sizeof(float2) + sizeof(float4) + sizeof(uint2));
     const size_t cursors = (n / 64) * sizeof(rrt::WfWaveCursor);
     const size_t rows = (n / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
-    return 2 * per_queue + cursors + rows + 256 + 12 * 256;  // every array is padded to 256 bytes
+    return (shadow ? 3 : 2) * per_queue + cursors + rows + 256 + 18 * 256;  // every array is padded to 256 bytes
 }
 
-int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity) {
-    if (be->wf_mem && be->wf_capacity == capacity) return RRT_OK;
+// shadow: with the queue of shadow rays (next-event estimation through the tree)
+int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity, bool shadow) {
+    if (be->wf_mem && be->wf_capacity == capacity && (be->wf_has_shadow || !shadow)) return RRT_OK;
     if (be->wf_mem) {
         HIP_TRY(hipStreamSynchronize(be->stream));
         HIP_TRY(hipFree(be->wf_mem));
         be->wf_mem = nullptr;
         be->wf_capacity = 0;
+        be->wf_has_shadow = false;
     }
     const size_t n = capacity;
     const size_t cursors = (n / 64) * sizeof(rrt::WfWaveCursor);
     const size_t rows = (n / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
-    HIP_TRY(hipMalloc(&be->wf_mem, wavefront_bytes(n)));
+    HIP_TRY(hipMalloc(&be->wf_mem, wavefront_bytes(n, shadow)));
     char* p = (char*)be->wf_mem;
     auto take = [&p](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
     // capacity is a multiple of 1024, so every array below is a multiple of 256 bytes long except
@@ -936,18 +937,28 @@ int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity) {
         wp.q[k].beta_pix = (float4*)take(n * sizeof(float4));
         wp.q[k].smp = (uint2*)take(n * sizeof(uint2));
     }
+    if (shadow) {
+        wp.sq.o_dx = (float4*)take(n * sizeof(float4));
+        wp.sq.dyz = (float2*)take(n * sizeof(float2));
+        wp.sq.hit = (float2*)take(n * sizeof(float2));
+        wp.sq.beta_pix = (float4*)take(n * sizeof(float4));
+        wp.sq.smp = (uint2*)take(n * sizeof(uint2));
+    }
     wp.cursors = (rrt::WfWaveCursor*)take(cursors);
     wp.block_counters = (unsigned long long*)take(rows);
     wp.ctl = (rrt::WfControl*)take(sizeof(rrt::WfControl));
     wp.capacity = capacity;
     be->wf_capacity = capacity;
+    be->wf_has_shadow = shadow;
     return RRT_OK;
 }
 
 // Runs the trips of the wavefront pipeline until every sample of the call is traced; fills
 // `counters` like the fused kernel does.
-int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_bvh, rrt::RenderParams rp,
+int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, const rrt::LightView<float>& lights, bool use_bvh, rrt::RenderParams rp,
                      unsigned long long* counters) {
+    const bool nee = (rp.flags & rrt::RENDER_FLAG_NEE) != 0;
+    const bool shadow_queue = nee && use_bvh;  // (the one-kernel-per-trip pipeline of scan scenes traces shadow rays on the spot)
     if (rp.max_depth > rrt::WF_MAX_DEPTH)
         return fail(RRT_ERR_UNSUPPORTED, "the wavefront pipeline packs the path depth into 9 bits: max_depth %u > %u",
                     rp.max_depth, rrt::WF_MAX_DEPTH);
@@ -963,11 +974,11 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
     {   // the queues must leave the caller at least half of what is free (counting the queues this backend already holds)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if (be->wf_mem) free_b += wavefront_bytes(be->wf_capacity);
-        while (capacity > kWfCapacityFloor && wavefront_bytes(capacity) > free_b / 2) capacity /= 2;
+        if (be->wf_mem) free_b += wavefront_bytes(be->wf_capacity, be->wf_has_shadow);
+        while (capacity > kWfCapacityFloor && wavefront_bytes(capacity, shadow_queue) > free_b / 2) capacity /= 2;
     }
     capacity = (capacity + block - 1) / block * block;
-    int rc = ensure_wavefront_buffers(be, capacity);
+    int rc = ensure_wavefront_buffers(be, capacity, shadow_queue);
     if (rc != RRT_OK) return rc;
     rrt::WfParams wp = be->wf;
     wp.stride_s = (uint32_t)(capacity / n_pixels);
@@ -986,7 +997,7 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
         // linear-scan scenes: one kernel per trip (closest hit fused into the shade kernel); the last trip's
         // output count is count[(trip + 1) % 3]
         for (uint64_t trip = 0;; ++trip) {
-            HIP_TRY(rrt::wf_launch_shade_scan(sv, rp, wp, trip, be->stream));
+            HIP_TRY(rrt::wf_launch_shade_scan(sv, lights, rp, wp, trip, be->stream));
             if (trip >= sure && (trip - sure) % check_every == 0) {
                 HIP_TRY(hipMemcpyAsync(&ctl, wp.ctl, sizeof(ctl), hipMemcpyDeviceToHost, be->stream));
                 HIP_TRY(hipStreamSynchronize(be->stream));
@@ -996,9 +1007,13 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
     } else {
         int parity = 0;
         for (uint64_t trip = 0;; ++trip) {
-            HIP_TRY(rrt::wf_launch_shade(sv, rp, wp, parity, be->stream));
+            HIP_TRY(rrt::wf_launch_shade(sv, lights, rp, wp, parity, be->stream));
             parity ^= 1;
-            HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, be->n_cu, be->stream));
+            HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, false, be->n_cu, be->stream));
+            if (shadow_queue) {  // the shadow rays that shade kernel queued: their own closest-hit launch, then what they carry
+                HIP_TRY(rrt::wf_launch_closest_hit(sv, use_bvh, wp, parity, true, be->n_cu, be->stream));
+                HIP_TRY(rrt::wf_launch_shadow_resolve(rp, wp, parity, be->stream));
+            }
             if (trip >= sure && (trip - sure) % check_every == 0) {
                 HIP_TRY(hipMemcpyAsync(&ctl, wp.ctl, sizeof(ctl), hipMemcpyDeviceToHost, be->stream));
                 HIP_TRY(hipStreamSynchronize(be->stream));
@@ -1014,8 +1029,8 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, bool use_
     for (int k = 0; k < rrt::COUNTER_COUNT; ++k) counters[k] = 0;
     for (size_t i = 0; i < rows.size(); ++i) counters[i % rrt::COUNTER_COUNT] += rows[i];
     counters[rrt::COUNTER_STACK_OVERFLOW] += dropped;
-    counters[rrt::COUNTER_RAYS] = ctl.rays;
-    if (!use_bvh) counters[rrt::COUNTER_PRIM_TESTS] = ctl.rays * (unsigned long long)sv.n_prims;
+    counters[rrt::COUNTER_RAYS] += ctl.rays;  // (the rows hold the shadow rays the one-kernel-per-trip pipeline traced on the spot)
+    if (!use_bvh) counters[rrt::COUNTER_PRIM_TESTS] = counters[rrt::COUNTER_RAYS] * (unsigned long long)sv.n_prims;
     return RRT_OK;
 }
 
@@ -1212,7 +1227,7 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     const bool use_bvh = kind >= 0;
     // AUTO: tree traversal wants many waves in flight, which the register-lean closest-hit kernel of
     // the wavefront pipeline has; a scan over a few primitives is fastest with the path in registers
-    const bool nee = (desc->flags & (RRT_RENDER_NEE | RRT_RENDER_EXACT_HITS)) != 0;  // flags that only the fused kernel serves
+    const bool nee = (desc->flags & RRT_RENDER_EXACT_HITS) != 0;  // a flag that only the fused kernel serves
     if ((desc->flags & RRT_RENDER_NEE) && ds->n_unbounded_lights > 0)
         return fail(RRT_ERR_UNSUPPORTED, "next-event estimation cannot sample the scene's %d emissive plane(s)", ds->n_unbounded_lights);
     const bool wavefront = desc->pipeline == RRT_PIPELINE_WAVEFRONT ||
@@ -1247,7 +1262,7 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     unsigned long long counter_rows[rrt::COUNTER_ROWS * rrt::COUNTER_COUNT];
     HIP_TRY(hipEventRecord(be->ev0, be->stream));
     if (desc->max_depth > 0 && wavefront) {
-        if ((rc = render_wavefront(be, with_tree(be, ds, ds->v32, kind), use_bvh, rp, counters)) != RRT_OK) return rc;
+        if ((rc = render_wavefront(be, with_tree(be, ds, ds->v32, kind), ds->l32, use_bvh, rp, counters)) != RRT_OK) return rc;
     } else if (desc->max_depth > 0) {
         if (desc->precision == RRT_PRECISION_F64)
             HIP_TRY(rrt::launch_render_fused(with_tree(be, ds, ds->v64, kind), ds->l64, use_bvh, rp, n_blocks, be->stream));

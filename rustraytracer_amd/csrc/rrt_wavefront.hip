@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) wf_init(RenderParams rp, WfParams wp) {
         wp.ctl->count[0] = wp.capacity;
         wp.ctl->count[1] = wp.ctl->count[2] = wp.ctl->count[3] = 0;
         wp.ctl->dyn[0] = wp.ctl->dyn[1] = 0;
+        wp.ctl->scount[0] = wp.ctl->scount[1] = wp.ctl->sdyn[0] = wp.ctl->sdyn[1] = 0;
         wp.ctl->rays = 0;
     }
 }
@@ -57,12 +58,16 @@ __global__ void __launch_bounds__(256) wf_init(RenderParams rp, WfParams wp) {
 // ------------------------------------------------------------------ closest hit
 // One ray per lane.  The linear scan reads primitive records wave-uniformly, so all 64 lanes of a
 // wave that holds at least one ray run it; lanes past the end of the queue repeat the last ray.
+// shadow: the queue of shadow rays (WfParams::sq) instead of the ray queue
 template <bool BVH>
-__global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> sv, WfParams wp, int parity) {
+__global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> sv, WfParams wp, int parity, int shadow) {
     __shared__ BlockCounters s_ctr;
-    const uint32_t n_in = wp.ctl->count[parity];
+    const uint32_t n_in = shadow ? wp.ctl->scount[parity] : wp.ctl->count[parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        wp.ctl->count[parity ^ 1] = 0;  // the output counter of the wf_shade that follows
+        if (!shadow) {
+            wp.ctl->count[parity ^ 1] = 0;   // the output counter of the wf_shade that follows
+            wp.ctl->scount[parity ^ 1] = 0;  // ... and its shadow rays
+        }
         wp.ctl->rays += n_in;
     }
     if (blockIdx.x * (uint32_t)WF_HIT_BLOCK >= n_in) return;
@@ -70,7 +75,7 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
         if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
         tree_top_load(sv);
     }
-    const WfQueue& q = wp.q[parity];
+    const WfQueue& q = shadow ? wp.sq : wp.q[parity];
     const uint32_t idx = blockIdx.x * (uint32_t)WF_HIT_BLOCK + threadIdx.x;
     const uint32_t j = idx < n_in ? idx : n_in - 1u;
     const float4 a = q.o_dx[j];
@@ -107,15 +112,19 @@ constexpr int WF_STACK_LEVELS = BVH_LDS_LEVELS;
 #define RRT_EXP_TREE_WAVES 8  // experiment: waves per SIMD the tree kernel is compiled for
 #endif
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(RRT_EXP_TREE_WAVES)))
-wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min) {
+wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min, int shadow) {
     typedef float R;
     __shared__ int s_stack[WF_STACK_LEVELS][BVH_BLOCK];
     __shared__ BlockCounters s_ctr;
     tree_top_load(sv);
     const int top_n = tree_top_count(sv);
-    const uint32_t n_in = wp.ctl->count[parity];
+    const uint32_t n_in = shadow ? wp.ctl->scount[parity] : wp.ctl->count[parity];
+    uint32_t* const dyn = shadow ? wp.ctl->sdyn : wp.ctl->dyn;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        wp.ctl->count[parity ^ 1] = 0;
+        if (!shadow) {
+            wp.ctl->count[parity ^ 1] = 0;
+            wp.ctl->scount[parity ^ 1] = 0;
+        }
         wp.ctl->rays += n_in;
     }
     // Which blocks of 64 rays this wave walks.  Nearly all of the queue is dealt out statically (wave w takes blocks
@@ -130,7 +139,7 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
 #define RRT_EXP_DYNAMIC_SHARE 64u  // 1 / this share of a trip's blocks is handed out dynamically
 #endif
     const uint32_t static_end = (n_ray_blocks - n_ray_blocks / RRT_EXP_DYNAMIC_SHARE) / stride * stride;
-    if (blockIdx.x == 0 && threadIdx.x == 0) wp.ctl->dyn[parity ^ 1] = 0;  // the next trip's counter
+    if (blockIdx.x == 0 && threadIdx.x == 0) dyn[parity ^ 1] = 0;  // the next trip's counter
     uint32_t blk = __builtin_amdgcn_readfirstlane(blockIdx.x * (BVH_BLOCK / 64) + (threadIdx.x >> 6));
     bool dynamic = false;
     auto next_block = [&]() {  // wave-uniform
@@ -140,19 +149,19 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
             dynamic = true;
         }
         uint32_t got = 0;
-        if ((threadIdx.x & 63u) == 0) got = atomicAdd(&wp.ctl->dyn[parity], 1u);
+        if ((threadIdx.x & 63u) == 0) got = atomicAdd(&dyn[parity], 1u);
         blk = static_end + __builtin_amdgcn_readfirstlane(got);
     };
     if (blk >= static_end) {
         dynamic = true;
         uint32_t got = 0;
-        if ((threadIdx.x & 63u) == 0) got = atomicAdd(&wp.ctl->dyn[parity], 1u);
+        if ((threadIdx.x & 63u) == 0) got = atomicAdd(&dyn[parity], 1u);
         blk = static_end + __builtin_amdgcn_readfirstlane(got);
     }
     if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
     __syncthreads();
     uint32_t off = 0;
-    const WfQueue& q = wp.q[parity];
+    const WfQueue& q = shadow ? wp.sq : wp.q[parity];
 
     int spill[BVH_STACK_ENTRIES - WF_STACK_LEVELS];  // (see TreeStackSpill)
     TreeWalk<R> w;
@@ -240,6 +249,13 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
             if (w.node >= 0) {
                 uint4 q0, q1, q2, q3;
                 tree_node_words(sv, w.node, top_n, q0, q1, q2, q3);
+#ifdef RRT_EXP_NODE128
+                {  // sensitivity experiment: a node step fetches 128 bytes (the record and its neighbour in the same 128-byte line pair)
+                    const uint4* nb = reinterpret_cast<const uint4*>(sv.nodes + (w.node ^ 1));
+                    const uint4 r0 = nb[0], r1 = nb[1], r2 = nb[2], r3 = nb[3];
+                    if ((r0.x ^ r1.y ^ r2.z ^ r3.w) == 0x12345678u) hc.node_tests += 1;
+                }
+#endif
 #ifdef RRT_EXP_EXTRA_VALU
                 {  // sensitivity experiment: extra dependent FMAs per node step
                     float x = __uint_as_float(q0.x);
@@ -300,14 +316,20 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
 // arithmetic overlaps the queue traffic.  The live counts then rotate through three words: this
 // trip reads count[c_in], adds to count[c_out] and clears the word the NEXT trip will add to (no
 // block of this launch touches that one).
-template <bool FUSE_HIT, int BLOCK>
+// NEE (RRT_RENDER_NEE, a separate instantiation): a lane at a Lambertian or Phong vertex samples a light and sends a
+// shadow ray -- traced on the spot by the wave-uniform scan (FUSE_HIT), or written to the shadow queue for the tree
+// kernel's next launch; wf_shadow_resolve then adds what the unblocked ones carry.  Whether the previous vertex sampled
+// the lights (an emitter found now then adds nothing) travels in bit 19 of the packed sampler word.
+template <bool FUSE_HIT, int BLOCK, bool NEE>
 __global__ void __launch_bounds__(BLOCK)
-wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in, int c_out, int c_clear, int first_trip) {
+wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lights, int parity, int c_in, int c_out, int c_clear, int first_trip) {
     typedef float R;
     constexpr int WAVES = BLOCK / 64;
     __shared__ BlockCounters s_ctr;
     __shared__ uint32_t s_wave_rays[WAVES];
     __shared__ uint32_t s_base;
+    __shared__ uint32_t s_wave_shadow[NEE && !FUSE_HIT ? WAVES : 1];
+    __shared__ uint32_t s_shadow_base;
 
     const uint32_t idx = blockIdx.x * (uint32_t)BLOCK + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63u;
@@ -336,6 +358,12 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
     MatRec<R> m;
     m.r = m.g = m.b = m.param = R(0);
     m.type = 0;
+    bool lights_sampled = false;
+    // the shadow ray of this lane's vertex (NEE)
+    bool shadow = false;
+    V3<R> s_wi = mk<R>(0, 0, 1), s_c = mk<R>(0, 0, 0);
+    R s_dist = R(0);
+    int s_prim = -2;
 
     int g = WF_EMPTY;
     float t_hit = 0.f;
@@ -372,17 +400,53 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
             path.smp.pixkey = pixel_key(rp.seed_lo, rp.seed_hi, pixel);
             path.smp.sample = s.x;
             path.smp.key = sample_key(path.smp.pixkey, s.x);
-            path.smp.ctr = s.y & 0xfffffu;
+            path.smp.ctr = s.y & 0x7ffffu;
+            lights_sampled = NEE && ((s.y >> 19) & 1u) != 0u;
             path.smp.dim = (s.y >> 20) & 7u;
             path.depth = s.y >> 23;
             V3<R> acc = mk<R>(0, 0, 0);
             const ShadeRec<R> sh = sv.shade[g];
             m = sv.mats[sh.object_id];
-            mode = process_hit<R>(rp, path, sh, m, t_hit, acc, n, bad, counted);
+            mode = process_hit<R>(rp, path, sh, m, t_hit, acc, n, bad, counted, !(NEE && lights_sampled));
             // only an emitter adds radiance, and it ends the path: at most one add per sample
             if (acc.x != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 0], acc.x);
             if (acc.y != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 1], acc.y);
             if (acc.z != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 2], acc.z);
+            if (NEE) {
+                if (mode == MAT_LAMBERTIAN || mode == MAT_PHONG) {
+                    // (process_hit has moved path.o to the vertex; path.d is still the incoming direction)
+                    const R pick = get_1d<R>(path.smp, rp, true);
+                    R lu, lv;
+                    get_draw<R>(path.smp, rp, true, lu, lv);
+                    V3<R> le_w;
+                    if (sample_light<R>(lights, path.o, pick, lu, lv, s_wi, s_dist, le_w, s_prim)) {
+                        const V3<R> f = lobe_bxdf_cos<R>(mode, path.d, n, m, s_wi);
+                        if (f.x != R(0) || f.y != R(0) || f.z != R(0)) {
+                            shadow = true;
+                            s_c = mk<R>(path.beta.x * f.x * le_w.x, path.beta.y * f.y * le_w.y, path.beta.z * f.z * le_w.z);
+                        }
+                    }
+                    lights_sampled = true;
+                } else if (mode != MODE_NEW) {
+                    lights_sampled = false;  // mirror, glass: the next vertex is found by the scattered ray alone
+                }
+            }
+        }
+    }
+    if (NEE && FUSE_HIT) {
+        // the shadow rays of this wave, by the same wave-uniform scan
+        const unsigned long long sm = __ballot(shadow);
+        if (sm) {
+            HitCounters hc{0, 0};
+            R ts;
+            const int gs = closest_hit<float, false>(sv, path.o, s_wi, ts, hc);
+            if (shadow && (gs < 0 || gs == s_prim || ts >= s_dist * (R(1) - nee_shadow_slack<R>()))) {
+                bad = bad || !(isfinite(s_c.x) && isfinite(s_c.y) && isfinite(s_c.z));
+                atomicAdd(&rp.accum[3 * (size_t)pixel + 0], s_c.x);
+                atomicAdd(&rp.accum[3 * (size_t)pixel + 1], s_c.y);
+                atomicAdd(&rp.accum[3 * (size_t)pixel + 2], s_c.z);
+            }
+            if (lane == 0) atomicAdd(&s_ctr.v[COUNTER_RAYS], (uint32_t)__popcll(sm));
         }
     }
 
@@ -414,6 +478,7 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
         if (start) {
             pixel = p;
             sampler_start(path.smp, rp, pixel_key(rp.seed_lo, rp.seed_hi, pixel), rp.sample_begin + s);
+            lights_sampled = false;
         }
         if (taken && lane == 0) {
             uint32_t off = cur.off + taken;
@@ -428,6 +493,8 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
     }
 
     // -- one draw for every lane that needs one, then the new ray
+    // (the vertex a shadow ray starts from is path.o; the scatter below replaces only the direction)
+    const V3<R> vertex = path.o;
     R u2 = R(0), v2 = R(0);
     if (start || mode_draws(mode)) get_draw<R>(path.smp, rp, start || mode_draws_2d(mode), u2, v2);
     bool have_ray = false;
@@ -448,10 +515,12 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
 
     // -- compaction
     const unsigned long long ray_mask = __ballot(have_ray);
+    const unsigned long long shadow_mask = (NEE && !FUSE_HIT) ? __ballot(shadow) : 0ull;
     const uint32_t c_start = (uint32_t)__popcll(__ballot(start));
     const uint32_t c_bad = (uint32_t)__popcll(__ballot(bad));
     if (lane == 0) {
         s_wave_rays[wave] = (uint32_t)__popcll(ray_mask);
+        if (NEE && !FUSE_HIT) s_wave_shadow[wave] = (uint32_t)__popcll(shadow_mask);
         if (c_start) atomicAdd(&s_ctr.v[COUNTER_SAMPLES], c_start);
         if (c_bad) atomicAdd(&s_ctr.v[COUNTER_NONFINITE], c_bad);
     }
@@ -465,6 +534,11 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
         uint32_t total = 0;
         for (int w = 0; w < WAVES; ++w) total += s_wave_rays[w];
         s_base = total ? atomicAdd(&wp.ctl->count[c_out], total) : 0u;
+        if (NEE && !FUSE_HIT) {
+            uint32_t st = 0;
+            for (int w = 0; w < WAVES; ++w) st += s_wave_shadow[w];
+            s_shadow_base = st ? atomicAdd(&wp.ctl->scount[c_out], st) : 0u;
+        }
     }
     __syncthreads();
     if (have_ray) {
@@ -473,8 +547,48 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, int parity, int c_in
         qo.o_dx[slot] = make_float4(path.o.x, path.o.y, path.o.z, path.d.x);
         qo.dyz[slot] = make_float2(path.d.y, path.d.z);
         qo.beta_pix[slot] = make_float4(path.beta.x, path.beta.y, path.beta.z, __uint_as_float(pixel));
-        qo.smp[slot] = make_uint2(path.smp.sample, path.smp.ctr | (path.smp.dim << 20) | (path.depth << 23));
+        qo.smp[slot] = make_uint2(path.smp.sample, path.smp.ctr | ((NEE && lights_sampled) ? (1u << 19) : 0u) | (path.smp.dim << 20) | (path.depth << 23));
     }
+    if (NEE && !FUSE_HIT) {
+        if (shadow) {
+            uint32_t slot = s_shadow_base + lane_rank(shadow_mask);
+            for (uint32_t w = 0; w < wave; ++w) slot += s_wave_shadow[w];
+            wp.sq.o_dx[slot] = make_float4(vertex.x, vertex.y, vertex.z, s_wi.x);
+            wp.sq.dyz[slot] = make_float2(s_wi.y, s_wi.z);
+            wp.sq.beta_pix[slot] = make_float4(s_c.x, s_c.y, s_c.z, __uint_as_float(pixel));
+            wp.sq.smp[slot] = make_uint2((uint32_t)(s_prim + 2), __float_as_uint(s_dist));
+        }
+    }
+    counters_flush(s_ctr, wp.block_counters);
+}
+
+// The shadow rays of one trip after their closest-hit launch: what an unblocked one carries goes to its pixel.
+// Unblocked: nothing on its way, the flat light's own primitive first, or nothing nearer than the sampled point.
+__global__ void __launch_bounds__(256) wf_shadow_resolve(RenderParams rp, WfParams wp, int parity) {
+    __shared__ BlockCounters s_ctr;
+    const uint32_t n_in = wp.ctl->scount[parity];
+    if (blockIdx.x * 256u >= n_in) return;
+    if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    bool bad = false;
+    if (i < n_in) {
+        const float2 h = wp.sq.hit[i];
+        const uint2 s = wp.sq.smp[i];
+        const int g = __float_as_int(h.y), light_prim = (int)s.x - 2;
+        const float dist = __uint_as_float(s.y);
+        if (g < 0 || g == light_prim || h.x >= dist * (1.f - nee_shadow_slack<float>())) {
+            const float4 c = wp.sq.beta_pix[i];
+            const uint32_t pixel = __float_as_uint(c.w);
+            bad = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 0], c.x);
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 1], c.y);
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 2], c.z);
+        }
+    }
+    const uint32_t c_bad = (uint32_t)__popcll(__ballot(bad));
+    if ((threadIdx.x & 63u) == 0 && c_bad) atomicAdd(&s_ctr.v[COUNTER_NONFINITE], c_bad);
+    __syncthreads();
     counters_flush(s_ctr, wp.block_counters);
 }
 
@@ -484,9 +598,10 @@ hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_
     return hipGetLastError();
 }
 
-hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity,
+hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity, bool shadow,
                                  int n_cu, hipStream_t stream) {
     const dim3 grid(wp.capacity / (uint32_t)WF_HIT_BLOCK), block(WF_HIT_BLOCK);
+    const int sh = shadow ? 1 : 0;
     if (bvh && sv.n_bvh_prims >= 2) {
         // persistent waves: as many blocks as the device holds at once, never more than there are rays
         // as many blocks as the device really holds at once (8 per CU with the kernel's registers and LDS; a block more
@@ -499,27 +614,38 @@ hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfP
         const uint32_t persistent_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
         const uint32_t want = grid.x < persistent_blocks ? grid.x : persistent_blocks;
         static const int refill_min = [] { const char* e = getenv("RRT_DEBUG_REFILL_MIN"); return e ? atoi(e) : WF_REFILL_MIN; }();  // experiments
-        hipLaunchKernelGGL(wf_closest_hit_tree, dim3(want), dim3(BVH_BLOCK), 0, stream, sv, wp, parity, refill_min);
+        hipLaunchKernelGGL(wf_closest_hit_tree, dim3(want), dim3(BVH_BLOCK), 0, stream, sv, wp, parity, refill_min, sh);
     } else if (bvh)
-        hipLaunchKernelGGL(wf_closest_hit<true>, grid, block, 0, stream, sv, wp, parity);
+        hipLaunchKernelGGL(wf_closest_hit<true>, grid, block, 0, stream, sv, wp, parity, sh);
     else
-        hipLaunchKernelGGL(wf_closest_hit<false>, grid, block, 0, stream, sv, wp, parity);
+        hipLaunchKernelGGL(wf_closest_hit<false>, grid, block, 0, stream, sv, wp, parity, sh);
     return hipGetLastError();
 }
 
-hipError_t wf_launch_shade(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp, int parity,
+hipError_t wf_launch_shade(const SceneView<float>& sv, const LightView<float>& lights, const RenderParams& rp, const WfParams& wp, int parity,
                            hipStream_t stream) {
-    hipLaunchKernelGGL((wf_shade<false, WF_SHADE_BLOCK>), dim3(wp.capacity / (uint32_t)WF_SHADE_BLOCK), dim3(WF_SHADE_BLOCK), 0, stream,
-                       sv, rp, wp, parity, parity, parity ^ 1, 0, 0);
+    const dim3 grid(wp.capacity / (uint32_t)WF_SHADE_BLOCK), block(WF_SHADE_BLOCK);
+    if (rp.flags & RENDER_FLAG_NEE)
+        hipLaunchKernelGGL((wf_shade<false, WF_SHADE_BLOCK, true>), grid, block, 0, stream, sv, rp, wp, lights, parity, parity, parity ^ 1, 0, 0);
+    else
+        hipLaunchKernelGGL((wf_shade<false, WF_SHADE_BLOCK, false>), grid, block, 0, stream, sv, rp, wp, lights, parity, parity, parity ^ 1, 0, 0);
     return hipGetLastError();
 }
 
-hipError_t wf_launch_shade_scan(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp,
+hipError_t wf_launch_shadow_resolve(const RenderParams& rp, const WfParams& wp, int parity, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_shadow_resolve, dim3((wp.capacity + 255u) / 256u), dim3(256), 0, stream, rp, wp, parity);
+    return hipGetLastError();
+}
+
+hipError_t wf_launch_shade_scan(const SceneView<float>& sv, const LightView<float>& lights, const RenderParams& rp, const WfParams& wp,
                                 unsigned long long trip, hipStream_t stream) {
     // 512 threads: with the scan's scalar registers a SIMD holds 7 waves, i.e. three blocks of 512 per CU but only one of 1024
-    hipLaunchKernelGGL((wf_shade<true, WF_SHADE_SCAN_BLOCK>), dim3(wp.capacity / (uint32_t)WF_SHADE_SCAN_BLOCK), dim3(WF_SHADE_SCAN_BLOCK), 0, stream,
-                       sv, rp, wp, (int)(trip & 1), (int)(trip % 3), (int)((trip + 1) % 3), (int)((trip + 2) % 3),
-                       trip == 0 ? 1 : 0);
+    const dim3 grid(wp.capacity / (uint32_t)WF_SHADE_SCAN_BLOCK), block(WF_SHADE_SCAN_BLOCK);
+    const int parity = (int)(trip & 1), c_in = (int)(trip % 3), c_out = (int)((trip + 1) % 3), c_clear = (int)((trip + 2) % 3), first = trip == 0 ? 1 : 0;
+    if (rp.flags & RENDER_FLAG_NEE)
+        hipLaunchKernelGGL((wf_shade<true, WF_SHADE_SCAN_BLOCK, true>), grid, block, 0, stream, sv, rp, wp, lights, parity, c_in, c_out, c_clear, first);
+    else
+        hipLaunchKernelGGL((wf_shade<true, WF_SHADE_SCAN_BLOCK, false>), grid, block, 0, stream, sv, rp, wp, lights, parity, c_in, c_out, c_clear, first);
     return hipGetLastError();
 }
 

@@ -21,16 +21,18 @@ struct WfQueue {
     float2* dyz;       // direction y, z
     float2* hit;       // t, scan-order primitive index as int bits (WF_MISS, WF_EMPTY)
     float4* beta_pix;  // throughput rgb, pixel index as uint bits
-    uint2* smp;        // sample index inside the pixel; draws | dimension << 20 | depth << 23
+    uint2* smp;        // sample index inside the pixel; draws | lights sampled at the previous vertex << 19 | dimension << 20 | depth << 23
 };
 
 enum : int { WF_MISS = -1, WF_EMPTY = -2 };
-constexpr uint32_t WF_MAX_DEPTH = 511;  // 9 bits of the packed sampler word
+constexpr uint32_t WF_MAX_DEPTH = 511;  // 9 bits of the packed sampler word (draws: 19 bits, lights sampled: 1, dimension: 3)
 
 struct WfControl {
     uint32_t count[4];        // live paths: count[parity] (two kernels per trip) or count[trip % 3] (one kernel per trip)
     unsigned long long rays;  // closest-hit queries so far
     uint32_t dyn[2];          // tree kernel: blocks of rays handed out dynamically in the trip of this parity
+    uint32_t scount[2];       // next-event estimation: shadow rays queued by the wf_shade that WROTE queue `parity`
+    uint32_t sdyn[2];         // ... and the tree kernel's dynamic share of them
     uint32_t pad[2];
 };
 
@@ -45,6 +47,10 @@ struct WfWaveCursor {
 
 struct WfParams {
     WfQueue q[2];
+    // Next-event estimation through the tree (RRT_RENDER_NEE): the shadow rays of a trip wait here for their own
+    // closest-hit launch.  o_dx / dyz: the ray; hit: what it met; beta_pix: the radiance it carries if nothing is in its
+    // way, and the pixel; smp: (the light's primitive + 2, the distance to the sampled point as float bits).
+    WfQueue sq;
     WfControl* ctl;
     WfWaveCursor* cursors;              // capacity / 64
     unsigned long long* block_counters; // rows of COUNTER_COUNT, one per block of the widest launch
@@ -59,12 +65,17 @@ constexpr int WF_HIT_BLOCK = 256;
 
 hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_t stream);
 // n_cu: compute units of the device (the tree kernel's grid is what they hold at once)
-hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity,
+// shadow = false: the rays of queue `parity`; true: the shadow rays queued by the wf_shade that wrote queue `parity`
+hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity, bool shadow,
                                  int n_cu, hipStream_t stream);
-hipError_t wf_launch_shade(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp, int parity,
+// lights.n > 0 with RENDER_FLAG_NEE in rp.flags: next-event estimation (shadow rays into wp.sq)
+hipError_t wf_launch_shade(const SceneView<float>& sv, const LightView<float>& lights, const RenderParams& rp, const WfParams& wp, int parity,
                            hipStream_t stream);
-// One kernel per trip for linear-scan scenes: closest hit + shade.  Trip t reads queue t & 1 and count[t % 3].
-hipError_t wf_launch_shade_scan(const SceneView<float>& sv, const RenderParams& rp, const WfParams& wp,
+// adds the radiance of the unblocked shadow rays of wp.sq (after their closest-hit launch) to the image
+hipError_t wf_launch_shadow_resolve(const RenderParams& rp, const WfParams& wp, int parity, hipStream_t stream);
+// One kernel per trip for linear-scan scenes: closest hit + shade (+ the shadow ray of next-event estimation, traced on
+// the spot).  Trip t reads queue t & 1 and count[t % 3].
+hipError_t wf_launch_shade_scan(const SceneView<float>& sv, const LightView<float>& lights, const RenderParams& rp, const WfParams& wp,
                                 unsigned long long trip, hipStream_t stream);
 
 }  // namespace rrt

@@ -11,12 +11,14 @@ import scenes_util as S
 pytestmark = pytest.mark.gpu
 
 
-def _compare(api, be, O, flat, rc, precision, max_bad, accel=None):
+def _compare(api, be, O, flat, rc, precision, max_bad, accel=None, pipeline=None):
     from rustraytracer_amd import _abi
     sc = api.Scene(flat)
     f64 = precision == api.PRECISION_F64
     dev, st = be.render_accumulate(sc, rc.render_desc(precision=precision, flags=_abi.RENDER_NEE,
-                                                       accel=api.ACCEL_AUTO if accel is None else accel))
+                                                       accel=api.ACCEL_AUTO if accel is None else accel,
+                                                       pipeline=api.PIPELINE_FUSED if pipeline is None else pipeline))
+    assert st["pipeline_used"] == (api.PIPELINE_FUSED if pipeline is None else pipeline)
     ref, rst = O.render_accumulate(flat, rc.render_desc(flags=_abi.RENDER_NEE), device_numbers=True if f64 else "f32")
     assert st["samples"] == rst["samples"] and st["nonfinite"] == 0 and rst["nonfinite"] == 0
     err = np.abs(dev.astype(np.float64) - ref)
@@ -37,12 +39,26 @@ def test_same_paths_f64(gpu, O, cfg, light):
         print(light, "pixels off:", _compare(api, be, O, flat, rc, api.PRECISION_F64, max_bad=4))
 
 
-def test_same_paths_f32(gpu, O, cfg, cornell):
+@pytest.mark.parametrize("pipeline", ["fused", "wavefront"])
+def test_same_paths_f32(gpu, O, cfg, cornell, pipeline):
+    """The product kernels, both pipelines: the fused kernel traces the shadow ray in the trip of its vertex, the
+    wavefront pipeline on the spot too for scan scenes and through a queue of shadow rays for tree scenes."""
     api, be = gpu
+    pl = api.PIPELINE_FUSED if pipeline == "fused" else api.PIPELINE_WAVEFRONT
     rc = cfg.stratified_config(64, 48, 6, 6, seed=43)
     # f32: a shadow ray that grazes an edge, or a light pick within an ulp of a table entry, goes the other way
-    for flat in (N.lit_room("pgram"), N.lit_room("sphere"), cornell):
-        print("pixels off:", _compare(api, be, O, flat, rc, api.PRECISION_F32, max_bad=24))
+    for flat in (N.lit_room("pgram"), N.lit_room("sphere"), N.lit_room("bent"), cornell):
+        for accel in (api.ACCEL_LINEAR, api.ACCEL_SAH_GPU):
+            print(pipeline, accel, "pixels off:", _compare(api, be, O, flat, rc, api.PRECISION_F32, max_bad=24, accel=accel, pipeline=pl))
+
+
+def test_wavefront_every_material_and_small_queues(gpu, O, cfg, monkeypatch):
+    """Every material, a tree, and queues far smaller than the frame (many trips, shadow queue refilled every trip)."""
+    api, be = gpu
+    monkeypatch.setenv("RRT_DEBUG_WF_CAPACITY", "4096")
+    rc = cfg.stratified_config(48, 36, 4, 4, min_depth=1, max_depth=8, seed=44)
+    for accel in (api.ACCEL_LINEAR, api.ACCEL_LBVH):
+        _compare(api, be, O, S.all_prims_scene(), rc, api.PRECISION_F32, max_bad=24, accel=accel, pipeline=api.PIPELINE_WAVEFRONT)
 
 
 def test_every_material_and_the_tree(gpu, O, cfg, cornell):
@@ -76,8 +92,8 @@ def test_refusals(gpu, cfg, cornell):
     from rustraytracer_amd import _abi
     api, be = gpu
     rc = cfg.stratified_config(16, 16, 2, 2)
-    with pytest.raises(api.RrtError):  # queues carry no light state
-        be.render_accumulate(api.Scene(cornell), rc.render_desc(flags=_abi.RENDER_NEE, pipeline=api.PIPELINE_WAVEFRONT))
+    with pytest.raises(api.RrtError):  # the wavefront queues are f32
+        be.render_accumulate(api.Scene(cornell), rc.render_desc(flags=_abi.RENDER_NEE, pipeline=api.PIPELINE_WAVEFRONT, precision=api.PRECISION_F64))
     with pytest.raises(api.RrtError):  # an emitting plane has no area to sample
         be.render_accumulate(api.Scene(N.emissive_plane_room()), rc.render_desc(flags=_abi.RENDER_NEE))
     with pytest.raises(api.RrtError):

@@ -118,10 +118,19 @@ def test_f32_kernels_at_benchmark_shapes(gpu, O, cfg, scenes, case):
                          cfg.stratified_config(256, 256, 8, 8, seed=54)),
     }[case]
     frac, rel_rays = _follow(api, be, O, flat, rc, api.PIPELINE_AUTO, case)
-    # a decision flipped by f32 rounding costs one SAMPLE, and a pixel with 16384 samples shows it: the gate is 0.5 % of
-    # the pixels or two flips per million samples, whichever is larger (measured: 2 of 4.2 M samples at 16384 spp)
     n_pixels, n_samples = rc.width * rc.height, rc.width * rc.height * rc.spp
-    assert frac * n_pixels <= max(0.005 * n_pixels, 2e-6 * n_samples) and rel_rays <= 1e-4
+    off_pixels = frac * n_pixels
+    assert rel_rays <= 1e-4
+    # Two gates, each where it means something.  A decision flipped by f32 rounding costs one SAMPLE and marks the pixel
+    # that holds it.  (1) Per sample: at most 15 flips per million samples (measured: 0.5 per million in the Cornell
+    # box at 16384 spp, 11 per million on smallpt's sphere silhouettes at 4 spp).  (2) Per pixel: at most 0.5 % of
+    # the pixels -- asked wherever a pixel holds few samples; a pixel that sums 16384 samples is marked by a single
+    # flip among them, so there the count of marked pixels IS the count of flips and gate (1) is the one that applies.
+    assert off_pixels <= 15e-6 * n_samples + 0.5, (case, off_pixels, n_samples)
+    if rc.spp <= 64:
+        assert frac <= 0.005, (case, frac)
+    else:
+        assert off_pixels <= 2e-6 * n_samples, (case, off_pixels)
 
 
 @pytest.mark.parametrize("name", ["cornell_box", "smallpt"])
