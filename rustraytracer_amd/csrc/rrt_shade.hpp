@@ -25,6 +25,16 @@ RRT_DEV R fresnel(R cos_i, R eta_i, R eta_t, R ratio) {
     R sin2_t = ratio * ratio * (R(1) - cos_i * cos_i);
     if (sin2_t > R(1)) return R(1);
     R cos_t = Num<R>::sqrt(R(1) - sin2_t);
+#ifdef RRT_EXP_FRESNEL_PK  // experiment: the two amplitude ratios side by side in packed arithmetic
+    if (sizeof(R) == 4) {
+        typedef float F2 __attribute__((ext_vector_type(2)));
+        const F2 a = {(float)eta_t, (float)eta_i}, b = {(float)eta_i, (float)eta_t};
+        const F2 x = a * (float)cos_i, y = b * (float)cos_t;
+        const F2 num = x - y, den = x + y;
+        const float r0 = num.x * Num<float>::rcp(den.x), r1 = num.y * Num<float>::rcp(den.y);
+        return (R)((r0 * r0 + r1 * r1) * 0.5f);
+    }
+#endif
     R r_ortho = (eta_t * cos_i - eta_i * cos_t) * Num<R>::rcp(eta_t * cos_i + eta_i * cos_t);
     R r_parallel = (eta_i * cos_i - eta_t * cos_t) * Num<R>::rcp(eta_i * cos_i + eta_t * cos_t);
     return (r_ortho * r_ortho + r_parallel * r_parallel) * R(0.5);

@@ -256,6 +256,12 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                     if ((r0.x ^ r1.y ^ r2.z ^ r3.w) == 0x12345678u) hc.node_tests += 1;
                 }
 #endif
+#ifdef RRT_EXP_NODE80
+                {  // sensitivity experiment: one more 16-byte load per node step (from the neighbouring record)
+                    const uint4 r0 = reinterpret_cast<const uint4*>(sv.nodes + (w.node ^ 1))[0];
+                    if ((r0.x ^ r0.y) == 0x12345678u) hc.node_tests += 1;
+                }
+#endif
 #ifdef RRT_EXP_EXTRA_VALU
                 {  // sensitivity experiment: extra dependent FMAs per node step
                     float x = __uint_as_float(q0.x);
@@ -281,6 +287,12 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
                 const int slot = v & BVH_SLOT_MASK;
                 const uint4* rec = reinterpret_cast<const uint4*>(sv.leaves + slot);
                 const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+#ifdef RRT_EXP_LEAF80
+                {  // sensitivity experiment: one more 16-byte load per leaf step
+                    const uint4 r0 = reinterpret_cast<const uint4*>(sv.leaves + (slot ^ 1))[0];
+                    if ((r0.x ^ r0.y) == 0x12345678u) hc.node_tests += 1;
+                }
+#endif
                 leaf_test_words<R>(sv, q0, q1, q2, q3, w.o, w.d, w.acc);
                 hc.prim_tests += 1;
                 const int left = v >> BVH_SLOT_BITS;
