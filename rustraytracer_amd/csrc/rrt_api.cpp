@@ -656,7 +656,9 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
             for (int k = 0; k < 3; ++k) { flo[k] = round_down(slo[k]); fhi[k] = round_up(shi[k]); }
             HIP_TRY(rrt::lbvh_build((const float*)dlo.p, (const float*)dhi.p, n, flo, fhi, (rrt::WideNode*)nodes, (int*)slots, be->stream, &depth));
         }
-        if (3 * depth > kTreeStackEntries) {  // too deep for the traversal stacks: median cuts instead
+        // RRT_DEBUG_MAX_TREE_DEPTH: tests only (a small limit sends an ordinary scene through the fallback)
+        static const int debug_depth = [] { const char* e = getenv("RRT_DEBUG_MAX_TREE_DEPTH"); return e ? atoi(e) : 0; }();
+        if (3 * depth > kTreeStackEntries || (debug_depth > 0 && depth > debug_depth)) {  // too deep for the traversal stacks: median cuts instead
             if ((rc = host_tree(true)) != RRT_OK) return rc;
             on_host = true;
             if (3 * depth > kTreeStackEntries)

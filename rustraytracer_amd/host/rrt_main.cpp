@@ -31,6 +31,8 @@ const char* kUsage =
     "      --pipeline <auto|fused|wavefront> kernel organisation [default: auto]\n"
     "      --next-event                     sample the lights at every Lambertian / Phong vertex (next-event estimation:\n"
     "                                       same image in the mean, less noise with small lights; not the reference's estimator)\n"
+    "      --exact-hits                     f32 only: repeat in f64 every closest-hit query that f32 cannot decide within its\n"
+    "                                       rounding-error bounds (slower; fused pipeline)\n"
     "      --stats-json <FILE>              write timings and counters of the run as JSON\n"
     "      --dump-scene <FILE>              write the flattened scene (binary) and exit without rendering\n"
     "  -h, --help                           Print help\n"
@@ -113,6 +115,8 @@ Args parse_args(int argc, char** argv) {
             a.pipeline = choice(arg, value(), n, 3);
         } else if (arg == "--next-event") {
             a.flags |= RRT_RENDER_NEE;
+        } else if (arg == "--exact-hits") {
+            a.flags |= RRT_RENDER_EXACT_HITS;
         } else if (arg == "--stats-json") {
             a.stats_json = value();
         } else if (arg == "--dump-scene") {
@@ -227,7 +231,13 @@ int run(const Args& a) {
         stats.prim_tests += part[g].prim_tests;
         stats.node_tests += part[g].node_tests;
         stats.nonfinite += part[g].nonfinite;
+        stats.exact_redos += part[g].exact_redos;
+        stats.stack_overflows += part[g].stack_overflows;
         stats.kernel_ms = std::max(stats.kernel_ms, part[g].kernel_ms);
+        stats.tree_build_ms = std::max(stats.tree_build_ms, part[g].tree_build_ms);
+        stats.accel_used = part[g].accel_used;  // (the same on every GPU: one scene, one description)
+        stats.pipeline_used = part[g].pipeline_used;
+        stats.tree_depth = part[g].tree_depth;
     }
     {   // mean -> tone map -> gamma -> white balance -> u8 on the first GPU; the divisor is samples_per_pixel
         // even where RandomSampler traced one sample more (src/sampler.rs:48-55, src/renderer.rs:128)
@@ -250,11 +260,13 @@ int run(const Args& a) {
         std::fprintf(f,
                      "{\"n_gpus\": %zu, \"width\": %u, \"height\": %u, \"spp\": %u, \"n_prims\": %zu, \"n_objects\": %zu, \"samples\": %llu, "
                      "\"rays\": %llu, \"prim_tests\": %llu, \"node_tests\": %llu, \"nonfinite\": %llu, \"load_s\": %.6f, "
-                     "\"render_s\": %.6f, \"kernel_s\": %.6f, \"total_s\": %.6f}\n",
+                     "\"render_s\": %.6f, \"kernel_s\": %.6f, \"total_s\": %.6f, \"accel_used\": %u, \"pipeline_used\": %u, "
+                     "\"tree_depth\": %u, \"tree_build_ms\": %.3f, \"exact_redos\": %llu, \"stack_overflows\": %llu}\n",
                      n_dev, rs.render.width, rs.render.height, rs.render.spp, sc.prims.size(), sc.materials.size(),
                      (unsigned long long)stats.samples, (unsigned long long)stats.rays, (unsigned long long)stats.prim_tests,
                      (unsigned long long)stats.node_tests, (unsigned long long)stats.nonfinite, t_load, render_s,
-                     stats.kernel_ms / 1e3, total_s);
+                     stats.kernel_ms / 1e3, total_s, stats.accel_used, stats.pipeline_used, stats.tree_depth, stats.tree_build_ms,
+                     (unsigned long long)stats.exact_redos, (unsigned long long)stats.stack_overflows);
         std::fclose(f);
     }
     return 0;

@@ -1,5 +1,6 @@
 // Host-only check of the surface-area tree builder (rustraytracer_amd/csrc/rrt_sah.hpp): structural
 // invariants on several inputs, and the same tree from one thread and from several.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -142,7 +143,41 @@ static void run(const char* name, const Input& in, int leaf_max) {
     std::printf("%-22s n %7d leaf_max %d: %7zu nodes, child area sum %.4g\n", name, in.n(), leaf_max, a.size(), sah_cost(a));
 }
 
+static int depth_of(const std::vector<BvhNode>& nodes) {  // levels of binary nodes (children are numbered above their parents)
+    std::vector<int> d(nodes.size(), 1);
+    int deepest = 1;
+    for (size_t i = 0; i < nodes.size(); ++i)
+        for (int32_t c : {nodes[i].c0, nodes[i].c1})
+            if (c >= 0) { d[(size_t)c] = d[i] + 1; deepest = std::max(deepest, d[(size_t)c]); }
+    return deepest;
+}
+
+// Median cuts (the fallback for trees too deep for the traversal stacks): the same invariants, and a depth of at most
+// ceil(log2 n) levels whatever the input -- here boxes nested like onion skins, which the cost function peels off one by
+// few into a tree three times as deep.
+static void run_median() {
+    Input in;
+    const int n = 2000;
+    float r = 1.f;
+    for (int i = 0; i < n; ++i, r *= 1.02f) {  // every skin 2 % larger than the one inside it
+        const float c[3] = {0.f, 0.f, 0.f}, h[3] = {r, r, r};
+        in.add(c, h);
+    }
+    std::vector<BvhNode> deep, flat;
+    std::vector<int32_t> od, of;
+    rrt::SahBuilder(in.lo.data(), in.hi.data(), n, 1).build(deep, od, 2);
+    rrt::SahBuilder(in.lo.data(), in.hi.data(), n, 1).build(flat, of, 2, true);
+    check_tree("onion, cost function", in, 1, deep, od);
+    check_tree("onion, median cuts", in, 1, flat, of);
+    int limit = 0;
+    while ((1 << limit) < n) ++limit;
+    std::printf("onion %d: %d levels with the cost function, %d with median cuts (limit %d)\n", n, depth_of(deep), depth_of(flat), limit);
+    CHECK(depth_of(flat) <= limit, "median cuts: %d levels for %d primitives", depth_of(flat), n);
+    CHECK(depth_of(deep) > 2 * limit, "the onion was meant to make a deep tree (%d levels)", depth_of(deep));
+}
+
 int main() {
+    run_median();
     for (int leaf_max : {1, 2, 4}) {
         run("two", random_boxes(2, 1, 1.f), leaf_max);
         run("three", random_boxes(3, 2, 1.f), leaf_max);

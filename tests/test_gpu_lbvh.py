@@ -332,3 +332,35 @@ def test_gpu_built_surface_area_tree_is_the_host_builders_tree(gpu, cfg, cornell
     _, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F32))
     if flat.n_prims > 72:
         assert st["accel_used"] == api.ACCEL_SAH_GPU and st["tree_built"] == 0
+
+
+def test_a_tree_too_deep_for_the_stacks_is_rebuilt_with_median_cuts(cfg):
+    """The traversal stacks hold three links per level of up to 48 levels; the library measures the depth of every tree
+    it builds and rebuilds a deeper one with median cuts (depth <= log2 n).  RRT_DEBUG_MAX_TREE_DEPTH lowers the limit
+    so that an ordinary mesh takes that path: still the scan's hits, bit for bit, a shallow tree, nothing dropped.
+    (A process of its own: the limit is read once per process.)"""
+    import subprocess
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["RRT_ROOT"]); sys.path.insert(0, os.path.join(os.environ["RRT_ROOT"], "tests"))
+import numpy as np
+from oracle import oracle_py as O
+from rustraytracer_amd import api, config
+import scenes_util as S
+import test_gpu_lbvh as T
+flat = T.mesh_scene(3000)
+be, sc = api.Backend(0), api.Scene(flat)
+o, d = S.secondary_rays(flat, O, 20000, seed=5)
+lin = be.intersect(sc, o, d, accel=api.ACCEL_LINEAR)
+rc = config.stratified_config(64, 64, 2, 2)
+for accel in (api.ACCEL_SAH_GPU, api.ACCEL_SAH, api.ACCEL_LBVH):
+    got = be.intersect(sc, o, d, accel=accel)
+    assert all(np.array_equal(a, b) for a, b in zip(lin, got)), accel
+    _, st = be.render_accumulate(sc, rc.render_desc(accel=accel))
+    assert st["tree_depth"] <= 12 and st["stack_overflows"] == 0, st   # ceil(log2 3000) = 12 binary levels at most
+    print("accel", accel, "depth", st["tree_depth"])
+print("fallback ok")
+'''
+    env = dict(os.environ, RRT_ROOT=ROOT, RRT_DEBUG_MAX_TREE_DEPTH="3")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
