@@ -81,9 +81,11 @@ typedef enum rrt_accel { RRT_ACCEL_AUTO = 0, RRT_ACCEL_LINEAR = 1, RRT_ACCEL_LBV
 /* Which kernel organisation renders.  FUSED keeps a path in registers for
  * all of its bounces and refills finished lanes with new camera samples;
  * WAVEFRONT keeps SoA ray and hit queues in HBM and compacts them after every
- * bounce (f32 only, max_depth <= 511).  AUTO: WAVEFRONT when the closest hit
- * goes through the tree of a scene with more than 150000 primitives and the
- * precision is f32, FUSED otherwise.  Both trace the same paths for the same seed. */
+ * bounce (max_depth <= 511; with RRT_PRECISION_F64 the queues hold doubles and the
+ * tree is walked one ray per lane: a checking mode, chosen only by name).  AUTO:
+ * WAVEFRONT when the closest hit goes through the tree of a scene with more than
+ * 150000 primitives and the precision is f32, FUSED otherwise.  Both trace the same
+ * paths for the same seed. */
 typedef enum rrt_pipeline { RRT_PIPELINE_AUTO = 0, RRT_PIPELINE_FUSED = 1, RRT_PIPELINE_WAVEFRONT = 2 } rrt_pipeline;
 
 /* Estimator switches.  0 everywhere in parity runs: the reference implements connect() for s = 0 only

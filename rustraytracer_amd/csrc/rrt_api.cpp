@@ -238,7 +238,7 @@ struct rrt_backend {
     void* wf_mem = nullptr;
     uint32_t wf_capacity = 0;
     bool wf_has_shadow = false;  // the shadow-ray queue of next-event estimation is part of wf_mem
-    rrt::WfParams wf{};
+    size_t wf_elem = 0;          // bytes per real number in the queues: 4 (f32, the product path) or 8
 };
 
 namespace {
@@ -905,59 +905,64 @@ const uint32_t kWfCapacityLinear = 1u << 24;
 const uint32_t kWfCapacityTree = 1u << 27;
 const uint32_t kWfCapacityFloor = 1u << 20;
 
-size_t wavefront_bytes(size_t n, bool shadow) {
-    const size_t per_queue = n * (sizeof(float4) + sizeof(float2) + sizeof(float2) + sizeof(float4) + sizeof(uint2));
+size_t wavefront_bytes(size_t n, bool shadow, size_t elem) {
+    const size_t per_queue = n * (12 * elem + sizeof(uint2));  // two 4-vectors, two 2-vectors, the packed sampler words
     const size_t cursors = (n / 64) * sizeof(rrt::WfWaveCursor);
     const size_t rows = (n / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
     return (shadow ? 3 : 2) * per_queue + cursors + rows + 256 + 18 * 256;  // every array is padded to 256 bytes
 }
 
+// The arrays of the queues inside the backend's one allocation.
+template <typename R>
+rrt::WfParams<R> wavefront_params(const rrt_backend* be) {
+    typedef typename rrt::WfElem<R>::V4 V4;
+    typedef typename rrt::WfElem<R>::V2 V2;
+    const size_t n = be->wf_capacity;
+    char* p = (char*)be->wf_mem;
+    auto take = [&p](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    // capacity is a multiple of 1024, so every array below is a multiple of 256 bytes long except
+    // the control block at the end, which the spare 256 bytes cover
+    rrt::WfParams<R> wp;
+    std::memset(&wp, 0, sizeof(wp));
+    auto carve = [&](rrt::WfQueue<R>& q) {
+        q.o_dx = (V4*)take(n * sizeof(V4));
+        q.dyz = (V2*)take(n * sizeof(V2));
+        q.hit = (V2*)take(n * sizeof(V2));
+        q.beta_pix = (V4*)take(n * sizeof(V4));
+        q.smp = (uint2*)take(n * sizeof(uint2));
+    };
+    carve(wp.q[0]);
+    carve(wp.q[1]);
+    if (be->wf_has_shadow) carve(wp.sq);
+    wp.cursors = (rrt::WfWaveCursor*)take((n / 64) * sizeof(rrt::WfWaveCursor));
+    wp.block_counters = (unsigned long long*)take((n / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long));
+    wp.ctl = (rrt::WfControl*)take(sizeof(rrt::WfControl));
+    wp.capacity = be->wf_capacity;
+    return wp;
+}
+
 // shadow: with the queue of shadow rays (next-event estimation through the tree)
-int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity, bool shadow) {
-    if (be->wf_mem && be->wf_capacity == capacity && (be->wf_has_shadow || !shadow)) return RRT_OK;
+int ensure_wavefront_buffers(rrt_backend* be, uint32_t capacity, bool shadow, size_t elem) {
+    if (be->wf_mem && be->wf_capacity == capacity && be->wf_elem == elem && (be->wf_has_shadow || !shadow)) return RRT_OK;
     if (be->wf_mem) {
         HIP_TRY(hipStreamSynchronize(be->stream));
         HIP_TRY(hipFree(be->wf_mem));
         be->wf_mem = nullptr;
         be->wf_capacity = 0;
         be->wf_has_shadow = false;
+        be->wf_elem = 0;
     }
-    const size_t n = capacity;
-    const size_t cursors = (n / 64) * sizeof(rrt::WfWaveCursor);
-    const size_t rows = (n / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
-    HIP_TRY(hipMalloc(&be->wf_mem, wavefront_bytes(n, shadow)));
-    char* p = (char*)be->wf_mem;
-    auto take = [&p](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
-    // capacity is a multiple of 1024, so every array below is a multiple of 256 bytes long except
-    // the control block at the end, which the spare 256 bytes cover
-    rrt::WfParams& wp = be->wf;
-    std::memset(&wp, 0, sizeof(wp));
-    for (int k = 0; k < 2; ++k) {
-        wp.q[k].o_dx = (float4*)take(n * sizeof(float4));
-        wp.q[k].dyz = (float2*)take(n * sizeof(float2));
-        wp.q[k].hit = (float2*)take(n * sizeof(float2));
-        wp.q[k].beta_pix = (float4*)take(n * sizeof(float4));
-        wp.q[k].smp = (uint2*)take(n * sizeof(uint2));
-    }
-    if (shadow) {
-        wp.sq.o_dx = (float4*)take(n * sizeof(float4));
-        wp.sq.dyz = (float2*)take(n * sizeof(float2));
-        wp.sq.hit = (float2*)take(n * sizeof(float2));
-        wp.sq.beta_pix = (float4*)take(n * sizeof(float4));
-        wp.sq.smp = (uint2*)take(n * sizeof(uint2));
-    }
-    wp.cursors = (rrt::WfWaveCursor*)take(cursors);
-    wp.block_counters = (unsigned long long*)take(rows);
-    wp.ctl = (rrt::WfControl*)take(sizeof(rrt::WfControl));
-    wp.capacity = capacity;
+    HIP_TRY(hipMalloc(&be->wf_mem, wavefront_bytes(capacity, shadow, elem)));
     be->wf_capacity = capacity;
     be->wf_has_shadow = shadow;
+    be->wf_elem = elem;
     return RRT_OK;
 }
 
 // Runs the trips of the wavefront pipeline until every sample of the call is traced; fills
 // `counters` like the fused kernel does.
-int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, const rrt::LightView<float>& lights, bool use_bvh, rrt::RenderParams rp,
+template <typename R>
+int render_wavefront(rrt_backend* be, const rrt::SceneView<R>& sv, const rrt::LightView<R>& lights, bool use_bvh, rrt::RenderParams rp,
                      unsigned long long* counters) {
     const bool nee = (rp.flags & rrt::RENDER_FLAG_NEE) != 0;
     const bool shadow_queue = nee && use_bvh;  // (the one-kernel-per-trip pipeline of scan scenes traces shadow rays on the spot)
@@ -976,13 +981,13 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<float>& sv, const rrt
     {   // the queues must leave the caller at least half of what is free (counting the queues this backend already holds)
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if (be->wf_mem) free_b += wavefront_bytes(be->wf_capacity, be->wf_has_shadow);
-        while (capacity > kWfCapacityFloor && wavefront_bytes(capacity, shadow_queue) > free_b / 2) capacity /= 2;
+        if (be->wf_mem) free_b += wavefront_bytes(be->wf_capacity, be->wf_has_shadow, be->wf_elem);
+        while (capacity > kWfCapacityFloor && wavefront_bytes(capacity, shadow_queue, sizeof(R)) > free_b / 2) capacity /= 2;
     }
     capacity = (capacity + block - 1) / block * block;
-    int rc = ensure_wavefront_buffers(be, capacity, shadow_queue);
+    int rc = ensure_wavefront_buffers(be, capacity, shadow_queue, sizeof(R));
     if (rc != RRT_OK) return rc;
-    rrt::WfParams wp = be->wf;
+    rrt::WfParams<R> wp = wavefront_params<R>(be);
     wp.stride_s = (uint32_t)(capacity / n_pixels);
     wp.stride_p = (uint32_t)(capacity % n_pixels);
     const size_t rows_bytes = (size_t)(capacity / rrt::WF_HIT_BLOCK) * rrt::COUNTER_COUNT * sizeof(unsigned long long);
@@ -1219,8 +1224,6 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
     if (!rgb_sum) return fail(RRT_ERR_INVALID, "rgb_sum is NULL");
     if ((rc = validate_render_desc(desc)) != RRT_OK) return rc;
-    if (desc->pipeline == RRT_PIPELINE_WAVEFRONT && desc->precision == RRT_PRECISION_F64)
-        return fail(RRT_ERR_UNSUPPORTED, "the wavefront pipeline keeps its queues in f32; use the fused pipeline for f64");
     DeviceScene* ds = nullptr;
     if ((rc = device_scene(be, scene, &ds)) != RRT_OK) return rc;
     int kind = -1;
@@ -1264,7 +1267,12 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
     unsigned long long counter_rows[rrt::COUNTER_ROWS * rrt::COUNTER_COUNT];
     HIP_TRY(hipEventRecord(be->ev0, be->stream));
     if (desc->max_depth > 0 && wavefront) {
-        if ((rc = render_wavefront(be, with_tree(be, ds, ds->v32, kind), ds->l32, use_bvh, rp, counters)) != RRT_OK) return rc;
+        // (f64: the same pipeline in the reference's arithmetic type, only when asked for by name)
+        if (desc->precision == RRT_PRECISION_F64)
+            rc = render_wavefront<double>(be, with_tree(be, ds, ds->v64, kind), ds->l64, use_bvh, rp, counters);
+        else
+            rc = render_wavefront<float>(be, with_tree(be, ds, ds->v32, kind), ds->l32, use_bvh, rp, counters);
+        if (rc != RRT_OK) return rc;
     } else if (desc->max_depth > 0) {
         if (desc->precision == RRT_PRECISION_F64)
             HIP_TRY(rrt::launch_render_fused(with_tree(be, ds, ds->v64, kind), ds->l64, use_bvh, rp, n_blocks, be->stream));

@@ -32,9 +32,11 @@ RRT_DEV void counters_flush(const BlockCounters& lds, unsigned long long* rows) 
 // ------------------------------------------------------------------ set-up
 // Marks every slot of queue 0 empty (the first wf_shade then fills it with camera samples),
 // positions the per-wave sample cursors and clears the control block.
-__global__ void __launch_bounds__(256) wf_init(RenderParams rp, WfParams wp) {
+template <typename R>
+__global__ void __launch_bounds__(256) wf_init(RenderParams rp, WfParams<R> wp) {
+    typedef WfElem<R> E;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < wp.capacity) wp.q[0].hit[i] = make_float2(0.f, __int_as_float(WF_EMPTY));
+    if (i < wp.capacity) wp.q[0].hit[i] = E::v2(R(0), E::of_int(WF_EMPTY));
     const uint32_t n_waves = wp.capacity / 64u;
     if (i < n_waves) {
         const unsigned long long first = (unsigned long long)i * 64ull;
@@ -59,8 +61,9 @@ __global__ void __launch_bounds__(256) wf_init(RenderParams rp, WfParams wp) {
 // One ray per lane.  The linear scan reads primitive records wave-uniformly, so all 64 lanes of a
 // wave that holds at least one ray run it; lanes past the end of the queue repeat the last ray.
 // shadow: the queue of shadow rays (WfParams::sq) instead of the ray queue
-template <bool BVH>
-__global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> sv, WfParams wp, int parity, int shadow) {
+template <typename R, bool BVH>
+__global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<R> sv, WfParams<R> wp, int parity, int shadow) {
+    typedef WfElem<R> E;
     __shared__ BlockCounters s_ctr;
     const uint32_t n_in = shadow ? wp.ctl->scount[parity] : wp.ctl->count[parity];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -75,15 +78,15 @@ __global__ void __launch_bounds__(WF_HIT_BLOCK) wf_closest_hit(SceneView<float> 
         if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
         tree_top_load(sv);
     }
-    const WfQueue& q = shadow ? wp.sq : wp.q[parity];
+    const WfQueue<R>& q = shadow ? wp.sq : wp.q[parity];
     const uint32_t idx = blockIdx.x * (uint32_t)WF_HIT_BLOCK + threadIdx.x;
     const uint32_t j = idx < n_in ? idx : n_in - 1u;
-    const float4 a = q.o_dx[j];
-    const float2 b = q.dyz[j];
+    const typename E::V4 a = q.o_dx[j];
+    const typename E::V2 b = q.dyz[j];
     HitCounters hc{0, 0};
-    float t;
-    const int g = closest_hit<float, BVH>(sv, mk<float>(a.x, a.y, a.z), mk<float>(a.w, b.x, b.y), t, hc);
-    if (idx < n_in) q.hit[idx] = make_float2(t, __int_as_float(g >= 0 ? g : WF_MISS));
+    R t;
+    const int g = closest_hit<R, BVH>(sv, mk<R>(a.x, a.y, a.z), mk<R>(a.w, b.x, b.y), t, hc);
+    if (idx < n_in) q.hit[idx] = E::v2(t, E::of_int(g >= 0 ? g : WF_MISS));
     if (BVH) {
         if (idx >= n_in) hc.prim_tests = hc.node_tests = 0;
         for (int off = 32; off > 0; off >>= 1) {
@@ -112,7 +115,7 @@ constexpr int WF_STACK_LEVELS = BVH_LDS_LEVELS;
 #define RRT_EXP_TREE_WAVES 8  // experiment: waves per SIMD the tree kernel is compiled for
 #endif
 __global__ void __launch_bounds__(BVH_BLOCK) __attribute__((amdgpu_waves_per_eu(RRT_EXP_TREE_WAVES)))
-wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min, int shadow) {
+wf_closest_hit_tree(SceneView<float> sv, WfParams<float> wp, int parity, int refill_min, int shadow) {
     typedef float R;
     __shared__ int s_stack[WF_STACK_LEVELS][BVH_BLOCK];
     __shared__ BlockCounters s_ctr;
@@ -161,7 +164,7 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
     if (threadIdx.x < COUNTER_COUNT) s_ctr.v[threadIdx.x] = 0;
     __syncthreads();
     uint32_t off = 0;
-    const WfQueue& q = shadow ? wp.sq : wp.q[parity];
+    const WfQueue<float>& q = shadow ? wp.sq : wp.q[parity];
 
     int spill[BVH_STACK_ENTRIES - WF_STACK_LEVELS];  // (see TreeStackSpill)
     TreeWalk<R> w;
@@ -332,10 +335,12 @@ wf_closest_hit_tree(SceneView<float> sv, WfParams wp, int parity, int refill_min
 // shadow ray -- traced on the spot by the wave-uniform scan (FUSE_HIT), or written to the shadow queue for the tree
 // kernel's next launch; wf_shadow_resolve then adds what the unblocked ones carry.  Whether the previous vertex sampled
 // the lights (an emitter found now then adds nothing) travels in bit 19 of the packed sampler word.
-template <bool FUSE_HIT, int BLOCK, bool NEE>
+template <typename R, bool FUSE_HIT, int BLOCK, bool NEE>
 __global__ void __launch_bounds__(BLOCK)
-wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lights, int parity, int c_in, int c_out, int c_clear, int first_trip) {
-    typedef float R;
+wf_shade(SceneView<R> sv, RenderParams rp, WfParams<R> wp, LightView<R> lights, int parity, int c_in, int c_out, int c_clear, int first_trip) {
+    typedef WfElem<R> E;
+    typedef typename E::V4 Q4;
+    typedef typename E::V2 Q2;
     constexpr int WAVES = BLOCK / 64;
     __shared__ BlockCounters s_ctr;
     __shared__ uint32_t s_wave_rays[WAVES];
@@ -347,8 +352,8 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lig
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t gwave = __builtin_amdgcn_readfirstlane(idx >> 6);
-    const WfQueue& qi = wp.q[parity];
-    const WfQueue& qo = wp.q[parity ^ 1];
+    const WfQueue<R>& qi = wp.q[parity];
+    const WfQueue<R>& qo = wp.q[parity ^ 1];
     const uint32_t n_in = wp.ctl->count[c_in];
     const uint32_t n_pixels = rp.width * rp.height;
     if (FUSE_HIT && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -378,37 +383,37 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lig
     int s_prim = -2;
 
     int g = WF_EMPTY;
-    float t_hit = 0.f;
+    R t_hit = R(0);
     if (FUSE_HIT) {
         // every lane of a wave that holds at least one ray runs the scan (wave-uniform loads)
         const bool have = idx < n_in && !first_trip;
         if (__ballot(have)) {
             const uint32_t j = have ? idx : 0u;
-            const float4 a = qi.o_dx[j];
-            const float2 b = qi.dyz[j];
+            const Q4 a = qi.o_dx[j];
+            const Q2 b = qi.dyz[j];
             path.o = mk<R>(a.x, a.y, a.z);
             path.d = mk<R>(a.w, b.x, b.y);
             HitCounters hc{0, 0};
-            const int found = closest_hit<float, false>(sv, path.o, path.d, t_hit, hc);
+            const int found = closest_hit<R, false>(sv, path.o, path.d, t_hit, hc);
             g = have ? (found >= 0 ? found : WF_MISS) : WF_EMPTY;
         }
     } else if (idx < n_in) {
-        const float2 h = qi.hit[idx];
+        const Q2 h = qi.hit[idx];
         t_hit = h.x;
-        g = __float_as_int(h.y);
+        g = E::to_int(h.y);
     }
     {
         if (g >= 0) {
             if (!FUSE_HIT) {
-                const float4 a = qi.o_dx[idx];
-                const float2 b = qi.dyz[idx];
+                const Q4 a = qi.o_dx[idx];
+                const Q2 b = qi.dyz[idx];
                 path.o = mk<R>(a.x, a.y, a.z);
                 path.d = mk<R>(a.w, b.x, b.y);
             }
-            const float4 c = qi.beta_pix[idx];
+            const Q4 c = qi.beta_pix[idx];
             const uint2 s = qi.smp[idx];
             path.beta = mk<R>(c.x, c.y, c.z);
-            pixel = __float_as_uint(c.w);
+            pixel = E::word_lo(c.w);
             path.smp.pixkey = pixel_key(rp.seed_lo, rp.seed_hi, pixel);
             path.smp.sample = s.x;
             path.smp.key = sample_key(path.smp.pixkey, s.x);
@@ -421,9 +426,9 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lig
             m = sv.mats[sh.object_id];
             mode = process_hit<R>(rp, path, sh, m, t_hit, acc, n, bad, counted, !(NEE && lights_sampled));
             // only an emitter adds radiance, and it ends the path: at most one add per sample
-            if (acc.x != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 0], acc.x);
-            if (acc.y != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 1], acc.y);
-            if (acc.z != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 2], acc.z);
+            if (acc.x != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 0], (float)acc.x);
+            if (acc.y != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 1], (float)acc.y);
+            if (acc.z != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 2], (float)acc.z);
             if (NEE) {
                 if (mode == MAT_LAMBERTIAN || mode == MAT_PHONG) {
                     // (process_hit has moved path.o to the vertex; path.d is still the incoming direction)
@@ -451,12 +456,12 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lig
         if (sm) {
             HitCounters hc{0, 0};
             R ts;
-            const int gs = closest_hit<float, false>(sv, path.o, s_wi, ts, hc);
+            const int gs = closest_hit<R, false>(sv, path.o, s_wi, ts, hc);
             if (shadow && (gs < 0 || gs == s_prim || ts >= s_dist * (R(1) - nee_shadow_slack<R>()))) {
                 bad = bad || !(isfinite(s_c.x) && isfinite(s_c.y) && isfinite(s_c.z));
-                atomicAdd(&rp.accum[3 * (size_t)pixel + 0], s_c.x);
-                atomicAdd(&rp.accum[3 * (size_t)pixel + 1], s_c.y);
-                atomicAdd(&rp.accum[3 * (size_t)pixel + 2], s_c.z);
+                atomicAdd(&rp.accum[3 * (size_t)pixel + 0], (float)s_c.x);
+                atomicAdd(&rp.accum[3 * (size_t)pixel + 1], (float)s_c.y);
+                atomicAdd(&rp.accum[3 * (size_t)pixel + 2], (float)s_c.z);
             }
             if (lane == 0) atomicAdd(&s_ctr.v[COUNTER_RAYS], (uint32_t)__popcll(sm));
         }
@@ -514,8 +519,15 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lig
         const uint32_t py = pixel / rp.width;  // (a multiply-shift with two more scalar registers costs this kernel 3 %)
         const R px_c = (R)(pixel - py * rp.width) + R(0.5);
         const R py_c = (R)py + R(0.5);
-        const R u = (px_c + u2) * rp.inv_width;  // src/renderer.rs:120-121
-        const R v = R(1) - (py_c + v2) * rp.inv_height;
+        // src/renderer.rs:120-121; f32 multiplies by a reciprocal prepared on the host, f64 divides like the reference
+        R u, v;
+        if constexpr (sizeof(R) == 4) {
+            u = (px_c + u2) * rp.inv_width;
+            v = R(1) - (py_c + v2) * rp.inv_height;
+        } else {
+            u = (px_c + u2) / (R)rp.width;
+            v = R(1) - (py_c + v2) / (R)rp.height;
+        }
         path.o = mk<R>(sv.cam_o[0], sv.cam_o[1], sv.cam_o[2]);
         path.d = camera_dir<R>(sv, u, v);
         path.beta = mk<R>(1, 1, 1);
@@ -556,19 +568,24 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lig
     if (have_ray) {
         uint32_t slot = s_base + lane_rank(ray_mask);
         for (uint32_t w = 0; w < wave; ++w) slot += s_wave_rays[w];
-        qo.o_dx[slot] = make_float4(path.o.x, path.o.y, path.o.z, path.d.x);
-        qo.dyz[slot] = make_float2(path.d.y, path.d.z);
-        qo.beta_pix[slot] = make_float4(path.beta.x, path.beta.y, path.beta.z, __uint_as_float(pixel));
+        qo.o_dx[slot] = E::v4(path.o.x, path.o.y, path.o.z, path.d.x);
+        qo.dyz[slot] = E::v2(path.d.y, path.d.z);
+        qo.beta_pix[slot] = E::v4(path.beta.x, path.beta.y, path.beta.z, E::of_words(pixel, 0u));
         qo.smp[slot] = make_uint2(path.smp.sample, path.smp.ctr | ((NEE && lights_sampled) ? (1u << 19) : 0u) | (path.smp.dim << 20) | (path.depth << 23));
     }
     if (NEE && !FUSE_HIT) {
         if (shadow) {
             uint32_t slot = s_shadow_base + lane_rank(shadow_mask);
             for (uint32_t w = 0; w < wave; ++w) slot += s_wave_shadow[w];
-            wp.sq.o_dx[slot] = make_float4(vertex.x, vertex.y, vertex.z, s_wi.x);
-            wp.sq.dyz[slot] = make_float2(s_wi.y, s_wi.z);
-            wp.sq.beta_pix[slot] = make_float4(s_c.x, s_c.y, s_c.z, __uint_as_float(pixel));
-            wp.sq.smp[slot] = make_uint2((uint32_t)(s_prim + 2), __float_as_uint(s_dist));
+            wp.sq.o_dx[slot] = E::v4(vertex.x, vertex.y, vertex.z, s_wi.x);
+            wp.sq.dyz[slot] = E::v2(s_wi.y, s_wi.z);
+            wp.sq.beta_pix[slot] = E::v4(s_c.x, s_c.y, s_c.z, E::of_words(pixel, (uint32_t)(s_prim + 2)));
+            if constexpr (sizeof(R) == 4) {
+                wp.sq.smp[slot] = make_uint2((uint32_t)(s_prim + 2), __float_as_uint(s_dist));
+            } else {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(s_dist);
+                wp.sq.smp[slot] = make_uint2((uint32_t)bits, (uint32_t)(bits >> 32));
+            }
         }
     }
     counters_flush(s_ctr, wp.block_counters);
@@ -576,7 +593,9 @@ wf_shade(SceneView<float> sv, RenderParams rp, WfParams wp, LightView<float> lig
 
 // The shadow rays of one trip after their closest-hit launch: what an unblocked one carries goes to its pixel.
 // Unblocked: nothing on its way, the flat light's own primitive first, or nothing nearer than the sampled point.
-__global__ void __launch_bounds__(256) wf_shadow_resolve(RenderParams rp, WfParams wp, int parity) {
+template <typename R>
+__global__ void __launch_bounds__(256) wf_shadow_resolve(RenderParams rp, WfParams<R> wp, int parity) {
+    typedef WfElem<R> E;
     __shared__ BlockCounters s_ctr;
     const uint32_t n_in = wp.ctl->scount[parity];
     if (blockIdx.x * 256u >= n_in) return;
@@ -585,17 +604,25 @@ __global__ void __launch_bounds__(256) wf_shadow_resolve(RenderParams rp, WfPara
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool bad = false;
     if (i < n_in) {
-        const float2 h = wp.sq.hit[i];
+        const typename E::V2 h = wp.sq.hit[i];
         const uint2 s = wp.sq.smp[i];
-        const int g = __float_as_int(h.y), light_prim = (int)s.x - 2;
-        const float dist = __uint_as_float(s.y);
-        if (g < 0 || g == light_prim || h.x >= dist * (1.f - nee_shadow_slack<float>())) {
-            const float4 c = wp.sq.beta_pix[i];
-            const uint32_t pixel = __float_as_uint(c.w);
+        const typename E::V4 c = wp.sq.beta_pix[i];
+        const int g = E::to_int(h.y);
+        int light_prim;
+        R dist;
+        if constexpr (sizeof(R) == 4) {
+            light_prim = (int)s.x - 2;
+            dist = __uint_as_float(s.y);
+        } else {
+            light_prim = (int)E::word_hi(c.w) - 2;
+            dist = __longlong_as_double((long long)(((unsigned long long)s.y << 32) | s.x));
+        }
+        if (g < 0 || g == light_prim || h.x >= dist * (R(1) - nee_shadow_slack<R>())) {
+            const uint32_t pixel = E::word_lo(c.w);
             bad = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
-            atomicAdd(&rp.accum[3 * (size_t)pixel + 0], c.x);
-            atomicAdd(&rp.accum[3 * (size_t)pixel + 1], c.y);
-            atomicAdd(&rp.accum[3 * (size_t)pixel + 2], c.z);
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 0], (float)c.x);
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 1], (float)c.y);
+            atomicAdd(&rp.accum[3 * (size_t)pixel + 2], (float)c.z);
         }
     }
     const uint32_t c_bad = (uint32_t)__popcll(__ballot(bad));
@@ -605,60 +632,85 @@ __global__ void __launch_bounds__(256) wf_shadow_resolve(RenderParams rp, WfPara
 }
 
 // ------------------------------------------------------------------ launchers
-hipError_t wf_launch_init(const RenderParams& rp, const WfParams& wp, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_init, dim3((wp.capacity + 255u) / 256u), dim3(256), 0, stream, rp, wp);
+template <typename R>
+hipError_t wf_launch_init(const RenderParams& rp, const WfParams<R>& wp, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_init<R>, dim3((wp.capacity + 255u) / 256u), dim3(256), 0, stream, rp, wp);
     return hipGetLastError();
 }
 
-hipError_t wf_launch_closest_hit(const SceneView<float>& sv, bool bvh, const WfParams& wp, int parity, bool shadow,
+namespace {
+// persistent waves through the tree (f32: the product path)
+void launch_tree_walk(const SceneView<float>& sv, const WfParams<float>& wp, int parity, int sh, int n_cu, uint32_t grid_x, hipStream_t stream) {
+    // as many blocks as the device really holds at once (8 per CU with the kernel's registers and LDS; a block more
+    // than fits would run after all the others, alone), never more than there are rays
+    static const int per_cu = [] {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_closest_hit_tree, BVH_BLOCK, 0) != hipSuccess || nb < 1) nb = 8;
+        return nb < 8 ? nb : 8;
+    }();
+    const uint32_t persistent_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
+    const uint32_t want = grid_x < persistent_blocks ? grid_x : persistent_blocks;
+    static const int refill_min = [] { const char* e = getenv("RRT_DEBUG_REFILL_MIN"); return e ? atoi(e) : WF_REFILL_MIN; }();  // experiments
+    hipLaunchKernelGGL(wf_closest_hit_tree, dim3(want), dim3(BVH_BLOCK), 0, stream, sv, wp, parity, refill_min, sh);
+}
+// f64 (checks against the oracle): one ray per lane from start to end, the walk the parity kernels use
+void launch_tree_walk(const SceneView<double>& sv, const WfParams<double>& wp, int parity, int sh, int, uint32_t grid_x, hipStream_t stream) {
+    hipLaunchKernelGGL((wf_closest_hit<double, true>), dim3(grid_x), dim3(WF_HIT_BLOCK), 0, stream, sv, wp, parity, sh);
+}
+}  // namespace
+
+template <typename R>
+hipError_t wf_launch_closest_hit(const SceneView<R>& sv, bool bvh, const WfParams<R>& wp, int parity, bool shadow,
                                  int n_cu, hipStream_t stream) {
     const dim3 grid(wp.capacity / (uint32_t)WF_HIT_BLOCK), block(WF_HIT_BLOCK);
     const int sh = shadow ? 1 : 0;
-    if (bvh && sv.n_bvh_prims >= 2) {
-        // persistent waves: as many blocks as the device holds at once, never more than there are rays
-        // as many blocks as the device really holds at once (8 per CU with the kernel's registers and LDS; a block more
-        // than fits would run after all the others, alone)
-        static const int per_cu = [] {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wf_closest_hit_tree, BVH_BLOCK, 0) != hipSuccess || nb < 1) nb = 8;
-            return nb < 8 ? nb : 8;
-        }();
-        const uint32_t persistent_blocks = (uint32_t)n_cu * (uint32_t)per_cu;
-        const uint32_t want = grid.x < persistent_blocks ? grid.x : persistent_blocks;
-        static const int refill_min = [] { const char* e = getenv("RRT_DEBUG_REFILL_MIN"); return e ? atoi(e) : WF_REFILL_MIN; }();  // experiments
-        hipLaunchKernelGGL(wf_closest_hit_tree, dim3(want), dim3(BVH_BLOCK), 0, stream, sv, wp, parity, refill_min, sh);
-    } else if (bvh)
-        hipLaunchKernelGGL(wf_closest_hit<true>, grid, block, 0, stream, sv, wp, parity, sh);
+    if (bvh && sv.n_bvh_prims >= 2)
+        launch_tree_walk(sv, wp, parity, sh, n_cu, grid.x, stream);
+    else if (bvh)
+        hipLaunchKernelGGL((wf_closest_hit<R, true>), grid, block, 0, stream, sv, wp, parity, sh);
     else
-        hipLaunchKernelGGL(wf_closest_hit<false>, grid, block, 0, stream, sv, wp, parity, sh);
+        hipLaunchKernelGGL((wf_closest_hit<R, false>), grid, block, 0, stream, sv, wp, parity, sh);
     return hipGetLastError();
 }
 
-hipError_t wf_launch_shade(const SceneView<float>& sv, const LightView<float>& lights, const RenderParams& rp, const WfParams& wp, int parity,
+template <typename R>
+hipError_t wf_launch_shade(const SceneView<R>& sv, const LightView<R>& lights, const RenderParams& rp, const WfParams<R>& wp, int parity,
                            hipStream_t stream) {
     const dim3 grid(wp.capacity / (uint32_t)WF_SHADE_BLOCK), block(WF_SHADE_BLOCK);
     if (rp.flags & RENDER_FLAG_NEE)
-        hipLaunchKernelGGL((wf_shade<false, WF_SHADE_BLOCK, true>), grid, block, 0, stream, sv, rp, wp, lights, parity, parity, parity ^ 1, 0, 0);
+        hipLaunchKernelGGL((wf_shade<R, false, WF_SHADE_BLOCK, true>), grid, block, 0, stream, sv, rp, wp, lights, parity, parity, parity ^ 1, 0, 0);
     else
-        hipLaunchKernelGGL((wf_shade<false, WF_SHADE_BLOCK, false>), grid, block, 0, stream, sv, rp, wp, lights, parity, parity, parity ^ 1, 0, 0);
+        hipLaunchKernelGGL((wf_shade<R, false, WF_SHADE_BLOCK, false>), grid, block, 0, stream, sv, rp, wp, lights, parity, parity, parity ^ 1, 0, 0);
     return hipGetLastError();
 }
 
-hipError_t wf_launch_shadow_resolve(const RenderParams& rp, const WfParams& wp, int parity, hipStream_t stream) {
-    hipLaunchKernelGGL(wf_shadow_resolve, dim3((wp.capacity + 255u) / 256u), dim3(256), 0, stream, rp, wp, parity);
+template <typename R>
+hipError_t wf_launch_shadow_resolve(const RenderParams& rp, const WfParams<R>& wp, int parity, hipStream_t stream) {
+    hipLaunchKernelGGL(wf_shadow_resolve<R>, dim3((wp.capacity + 255u) / 256u), dim3(256), 0, stream, rp, wp, parity);
     return hipGetLastError();
 }
 
-hipError_t wf_launch_shade_scan(const SceneView<float>& sv, const LightView<float>& lights, const RenderParams& rp, const WfParams& wp,
+template <typename R>
+hipError_t wf_launch_shade_scan(const SceneView<R>& sv, const LightView<R>& lights, const RenderParams& rp, const WfParams<R>& wp,
                                 unsigned long long trip, hipStream_t stream) {
     // 512 threads: with the scan's scalar registers a SIMD holds 7 waves, i.e. three blocks of 512 per CU but only one of 1024
     const dim3 grid(wp.capacity / (uint32_t)WF_SHADE_SCAN_BLOCK), block(WF_SHADE_SCAN_BLOCK);
     const int parity = (int)(trip & 1), c_in = (int)(trip % 3), c_out = (int)((trip + 1) % 3), c_clear = (int)((trip + 2) % 3), first = trip == 0 ? 1 : 0;
     if (rp.flags & RENDER_FLAG_NEE)
-        hipLaunchKernelGGL((wf_shade<true, WF_SHADE_SCAN_BLOCK, true>), grid, block, 0, stream, sv, rp, wp, lights, parity, c_in, c_out, c_clear, first);
+        hipLaunchKernelGGL((wf_shade<R, true, WF_SHADE_SCAN_BLOCK, true>), grid, block, 0, stream, sv, rp, wp, lights, parity, c_in, c_out, c_clear, first);
     else
-        hipLaunchKernelGGL((wf_shade<true, WF_SHADE_SCAN_BLOCK, false>), grid, block, 0, stream, sv, rp, wp, lights, parity, c_in, c_out, c_clear, first);
+        hipLaunchKernelGGL((wf_shade<R, true, WF_SHADE_SCAN_BLOCK, false>), grid, block, 0, stream, sv, rp, wp, lights, parity, c_in, c_out, c_clear, first);
     return hipGetLastError();
 }
+
+#define RRT_WF_INSTANTIATE(R)                                                                                                              \
+    template hipError_t wf_launch_init<R>(const RenderParams&, const WfParams<R>&, hipStream_t);                                           \
+    template hipError_t wf_launch_closest_hit<R>(const SceneView<R>&, bool, const WfParams<R>&, int, bool, int, hipStream_t);              \
+    template hipError_t wf_launch_shade<R>(const SceneView<R>&, const LightView<R>&, const RenderParams&, const WfParams<R>&, int, hipStream_t); \
+    template hipError_t wf_launch_shadow_resolve<R>(const RenderParams&, const WfParams<R>&, int, hipStream_t);                            \
+    template hipError_t wf_launch_shade_scan<R>(const SceneView<R>&, const LightView<R>&, const RenderParams&, const WfParams<R>&, unsigned long long, hipStream_t);
+RRT_WF_INSTANTIATE(float)
+RRT_WF_INSTANTIATE(double)
+#undef RRT_WF_INSTANTIATE
 
 }  // namespace rrt

@@ -19,13 +19,17 @@ import scenes_util as S
 pytestmark = pytest.mark.gpu
 
 
-def _compare(api, be, O, cfg, flat, rc, max_bad, accel=None):
+def _compare(api, be, O, cfg, flat, rc, max_bad, accel=None, pipeline=None):
     sc = api.Scene(flat)
-    dev, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64, accel=api.ACCEL_AUTO if accel is None else accel))
+    dev, st = be.render_accumulate(sc, rc.render_desc(precision=api.PRECISION_F64, accel=api.ACCEL_AUTO if accel is None else accel,
+                                                       pipeline=api.PIPELINE_AUTO if pipeline is None else pipeline))
+    if pipeline is not None:
+        assert st["pipeline_used"] == pipeline
     ref, rst = O.render_accumulate(flat, rc.render_desc(), device_numbers=True)
     assert st["samples"] == rst["samples"] and st["nonfinite"] == 0 and rst["nonfinite"] == 0
     err = np.abs(dev.astype(np.float64) - ref)
-    tol = 4e-7 * np.abs(ref) + 1e-9  # f32 storage of (a few) f64 item sums
+    # f32 storage of (a few) f64 item sums; the wavefront pipeline adds every sample's radiance to the f32 sum by itself
+    tol = (4e-7 if pipeline != api.PIPELINE_WAVEFRONT else 3e-7 * np.sqrt(rc.spp)) * np.abs(ref) + 1e-9
     bad = int(np.any(err > tol, axis=-1).sum())
     assert bad <= max_bad, (bad, float(err.max()))
     # the same paths: the same number of closest-hit queries (the oracle also counts queries of paths whose
@@ -50,6 +54,24 @@ def test_every_primitive_and_material_same_paths(gpu, O, cfg):
     for rc in (cfg.stratified_config(80, 60, 6, 6, min_depth=1, max_depth=8, seed=23),
                cfg.random_config(48, 48, 16, min_depth=0, max_depth=5, seed=24)):
         _compare(api, be, O, cfg, flat, rc, max_bad=4)
+
+
+def test_wavefront_pipeline_in_f64_same_paths(gpu, O, cfg, scenes, cornell):
+    """The queue pipeline in the reference's arithmetic type: the one-kernel-per-trip form of scan scenes and the
+    closest-hit + shade pair of tree scenes trace the oracle's paths, like the fused kernel."""
+    api, be = gpu
+    wf = api.PIPELINE_WAVEFRONT
+    for name in ("cornell_box", "smallpt"):
+        bad = _compare(api, be, O, cfg, scenes[name], cfg.stratified_config(96, 72, 6, 6, seed=41), max_bad=3, accel=api.ACCEL_LINEAR, pipeline=wf)
+        print(name, "scan, pixels off:", bad)
+    _compare(api, be, O, cfg, cornell, cfg.random_config(64, 48, 24, seed=42), max_bad=3, accel=api.ACCEL_LINEAR, pipeline=wf)
+    for tree in (api.ACCEL_LBVH, api.ACCEL_SAH_GPU):
+        _compare(api, be, O, cfg, cornell, cfg.stratified_config(64, 64, 4, 4, seed=43), max_bad=3, accel=tree, pipeline=wf)
+        _compare(api, be, O, cfg, S.all_prims_scene(), cfg.stratified_config(64, 48, 4, 4, min_depth=1, max_depth=8, seed=44), max_bad=4,
+                 accel=tree, pipeline=wf)
+    flat = _two_mesh_scene(5000)
+    bad = _compare(api, be, O, cfg, flat, cfg.stratified_config(64, 48, 3, 3, seed=45), max_bad=4, accel=api.ACCEL_SAH_GPU, pipeline=wf)
+    print("10 000 triangles, pixels off:", bad)
 
 
 def test_same_paths_through_the_tree(gpu, O, cfg, cornell):

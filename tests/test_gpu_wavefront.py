@@ -85,9 +85,6 @@ def test_furnace_and_shards(gpu, cfg, cornell):
 def test_wavefront_rejects_what_it_cannot_do(gpu, cfg, cornell):
     api, be = gpu
     sc = api.Scene(cornell)
-    rc = cfg.stratified_config(8, 8, 2, 2)
-    with pytest.raises(api.RrtError):
-        be.render_accumulate(sc, rc.render_desc(pipeline=api.PIPELINE_WAVEFRONT, precision=api.PRECISION_F64))
     rc = cfg.stratified_config(8, 8, 2, 2, max_depth=600)
     with pytest.raises(api.RrtError):
         be.render_accumulate(sc, rc.render_desc(pipeline=api.PIPELINE_WAVEFRONT))
