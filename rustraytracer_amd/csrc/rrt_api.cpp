@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <new>
@@ -564,32 +565,76 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
     // camera (every other ray starts on a surface).  The slab tests are exact up to a few f32 ulps
     // of the distance between ray origin and box, and the f32 primitive tests accept points a few
     // 1e-7 (relative to that scale) outside the exact primitive; the boxes are padded for both.
+    // (three passes over the primitives: which are in the tree and the scale; their indices; their boxes.  The first
+    // and the last run on the host's threads: alone they took 40 of the 80 ms of a million-triangle build.)
+    static const bool print_times = getenv("RRT_DEBUG_BUILD_TIMES") != nullptr;  // developer switch: phases to stderr
+    auto since = [&t_begin]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    const size_t n_all = sc->prims.size();
+    const int n_threads = n_all < 20000 ? 1 : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    // fn(thread, begin, end) over [0, count) in contiguous shares; falls back to the calling thread when no thread can be had
+    auto in_shares = [n_threads](size_t count, const std::function<void(int, size_t, size_t)>& fn) {
+        std::vector<std::thread> pool;
+        const size_t per = (count + (size_t)n_threads - 1) / (size_t)n_threads;
+        int started = 1;
+        try {
+            for (; started < n_threads; ++started) {
+                const size_t b = std::min(count, per * (size_t)started), e = std::min(count, b + per);
+                pool.emplace_back(fn, started, b, e);
+            }
+        } catch (const std::system_error&) {
+        }
+        fn(0, 0, std::min(count, per));
+        for (std::thread& t : pool) t.join();
+        if (started < n_threads) fn(started, std::min(count, per * (size_t)started), count);  // what the missing threads would have done
+    };
+    std::vector<uint8_t> outside(n_all);
     double scale = 0;
-    for (int k = 0; k < 3; ++k) scale = std::fmax(scale, std::fabs(sc->camera.origin[k]));
-    for (const rrt_prim& p : sc->prims) {
-        if (outside_tree(p)) continue;
-        double blo[3], bhi[3];
-        bounds(p, blo, bhi);
-        for (int k = 0; k < 3; ++k) scale = std::fmax(scale, std::fmax(std::fabs(blo[k]), std::fabs(bhi[k])));
+    try {
+        std::vector<double> share_scale((size_t)n_threads, 0.0);
+        in_shares(n_all, [&](int t, size_t b, size_t e) {
+            double m = 0;
+            for (size_t g = b; g < e; ++g) {
+                const rrt_prim& p = sc->prims[g];
+                outside[g] = outside_tree(p) ? 1 : 0;
+                if (outside[g]) continue;
+                double blo[3], bhi[3];
+                bounds(p, blo, bhi);
+                for (int k = 0; k < 3; ++k) m = std::fmax(m, std::fmax(std::fabs(blo[k]), std::fabs(bhi[k])));
+            }
+            share_scale[(size_t)t] = std::fmax(share_scale[(size_t)t], m);
+        });
+        for (int k = 0; k < 3; ++k) scale = std::fmax(scale, std::fabs(sc->camera.origin[k]));
+        for (double m : share_scale) scale = std::fmax(scale, m);
+        for (size_t g = 0; g < n_all; ++g) (outside[g] ? unbounded : bounded).push_back((int32_t)g);
+        lo.resize(3 * bounded.size());
+        hi.resize(3 * bounded.size());
+        std::vector<double> share_box((size_t)n_threads * 6);
+        for (int t = 0; t < n_threads; ++t)
+            for (int k = 0; k < 3; ++k) { share_box[(size_t)t * 6 + k] = INFINITY; share_box[(size_t)t * 6 + 3 + k] = -INFINITY; }
+        in_shares(bounded.size(), [&](int t, size_t b, size_t e) {
+            double* box = share_box.data() + (size_t)t * 6;
+            for (size_t i = b; i < e; ++i) {
+                double blo[3], bhi[3];
+                bounds(sc->prims[(size_t)bounded[i]], blo, bhi);
+                double ext = std::fmax(std::fmax(bhi[0] - blo[0], bhi[1] - blo[1]), bhi[2] - blo[2]);
+                double pad = 1e-4 * ext + 4e-6 * scale + 1e-30;
+                for (int k = 0; k < 3; ++k) {
+                    lo[3 * i + k] = round_down(blo[k] - pad);
+                    hi[3 * i + k] = round_up(bhi[k] + pad);
+                    box[k] = std::fmin(box[k], blo[k]);
+                    box[3 + k] = std::fmax(box[3 + k], bhi[k]);
+                }
+            }
+        });
+        for (int t = 0; t < n_threads; ++t)
+            for (int k = 0; k < 3; ++k) {
+                slo[k] = std::fmin(slo[k], share_box[(size_t)t * 6 + k]);
+                shi[k] = std::fmax(shi[k], share_box[(size_t)t * 6 + 3 + k]);
+            }
+    } catch (const std::bad_alloc&) {
+        return fail(RRT_ERR_NOMEM, "out of host memory while preparing the tree of %zu primitives", n_all);
     }
-    for (size_t g = 0; g < sc->prims.size(); ++g) {
-        const rrt_prim& p = sc->prims[g];
-        if (outside_tree(p)) {
-            unbounded.push_back((int32_t)g);
-            continue;
-        }
-        double blo[3], bhi[3];
-        bounds(p, blo, bhi);
-        double ext = std::fmax(std::fmax(bhi[0] - blo[0], bhi[1] - blo[1]), bhi[2] - blo[2]);
-        double pad = 1e-4 * ext + 4e-6 * scale + 1e-30;
-        for (int k = 0; k < 3; ++k) {
-            lo.push_back(round_down(blo[k] - pad));
-            hi.push_back(round_up(bhi[k] + pad));
-            slo[k] = std::fmin(slo[k], blo[k]);
-            shi[k] = std::fmax(shi[k], bhi[k]);
-        }
-        bounded.push_back((int32_t)g);
-    }
+    if (print_times) fprintf(stderr, "[rrt] tree build: boxes of %zu primitives on %d thread(s) at %.1f ms\n", n_all, n_threads, since());
     if (bounded.size() > (size_t)rrt::BVH_MAX_PRIMS)
         return fail(RRT_ERR_UNSUPPORTED, "the LBVH addresses at most %d bounded primitives", rrt::BVH_MAX_PRIMS);
     const int n = (int)bounded.size();
@@ -632,12 +677,15 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
         } else if (kind == 2) {
             // the builder's fourth cut coordinate, as SahBuilder::build computes it (so that both bin the same numbers)
             std::vector<float> size((size_t)n);
-            for (int i = 0; i < n; ++i) {
-                rrt::SahBox b;
-                b.clear();
-                b.grow(lo.data() + 3 * (size_t)i, hi.data() + 3 * (size_t)i);
-                size[(size_t)i] = std::log2(std::max(b.half_area(), 1e-30f));
-            }
+            in_shares((size_t)n, [&](int, size_t b0, size_t e0) {
+                for (size_t i = b0; i < e0; ++i) {
+                    rrt::SahBox b;
+                    b.clear();
+                    b.grow(lo.data() + 3 * i, hi.data() + 3 * i);
+                    size[i] = std::log2(std::max(b.half_area(), 1e-30f));
+                }
+            });
+            if (print_times) fprintf(stderr, "[rrt] tree build: cut coordinates at %.1f ms\n", since());
             DevBuf dlo, dhi, dsize;
             HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));
             HIP_TRY(dhi.alloc(sizeof(float) * 3 * n));
@@ -664,6 +712,7 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
             if (3 * depth > kTreeStackEntries)
                 return fail(RRT_ERR_UNSUPPORTED, "the tree of %d primitives is %d levels deep; the traversal stacks hold %d", n, depth, kTreeStackEntries / 3);
         }
+        if (print_times) { (void)hipStreamSynchronize(be->stream); fprintf(stderr, "[rrt] tree build: tree and wide nodes at %.1f ms\n", since()); }
         if (!on_host) {
             map.resize((size_t)n);
             HIP_TRY(hipMemcpy(map.data(), slots, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost));
@@ -690,6 +739,7 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
         tree.leaves64 = (const rrt::LeafRec<double>*)l64;
     }
     HIP_TRY(hipStreamSynchronize(be->stream));
+    if (print_times) fprintf(stderr, "[rrt] tree build: leaf records at %.1f ms\n", since());
     tree.nodes = d_nodes;
     tree.bvh_prim = d_slot;
     tree.linear_prim = d_lin;
