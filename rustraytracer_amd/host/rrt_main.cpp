@@ -33,13 +33,19 @@ const char* kUsage =
     "                                       same image in the mean, less noise with small lights; not the reference's estimator)\n"
     "      --exact-hits                     f32 only: repeat in f64 every closest-hit query that f32 cannot decide within its\n"
     "                                       rounding-error bounds (slower; fused pipeline)\n"
+    "      --checkpoint <FILE>              render the sample indices in portions and keep the radiance sums and the next\n"
+    "                                       index in FILE after each; a run that finds FILE (same scene, image, sampler,\n"
+    "                                       seed) goes on where it stopped (the reference writes its image once, at the end)\n"
+    "      --checkpoint-every <N>           sample indices per portion [default: an eighth of the render]\n"
     "      --stats-json <FILE>              write timings and counters of the run as JSON\n"
     "      --dump-scene <FILE>              write the flattened scene (binary) and exit without rendering\n"
     "  -h, --help                           Print help\n"
     "  -V, --version                        Print version\n";
 
 struct Args {
-    std::string scene, render, output, stats_json, dump_scene;
+    std::string scene, render, output, stats_json, dump_scene, checkpoint;
+    unsigned long long checkpoint_every = 0;
+    long stop_after_portions = -1;  // developer switch: leave with status 3 after this many portions, as an interrupted run would
     int device = 0;
     std::vector<int> devices;
     bool has_seed = false;
@@ -117,6 +123,13 @@ Args parse_args(int argc, char** argv) {
             a.flags |= RRT_RENDER_NEE;
         } else if (arg == "--exact-hits") {
             a.flags |= RRT_RENDER_EXACT_HITS;
+        } else if (arg == "--checkpoint") {
+            a.checkpoint = value();
+        } else if (arg == "--checkpoint-every") {
+            a.checkpoint_every = std::strtoull(value().c_str(), nullptr, 10);
+            if (a.checkpoint_every == 0) usage_error("invalid value for '--checkpoint-every'");
+        } else if (arg == "--stop-after-portions") {
+            a.stop_after_portions = std::atol(value().c_str());
         } else if (arg == "--stats-json") {
             a.stats_json = value();
         } else if (arg == "--dump-scene") {
@@ -139,6 +152,7 @@ Args parse_args(int argc, char** argv) {
         }
     }
     if (a.scene.empty()) usage_error("the following required arguments were not provided: --scene-config <SCENE_CONFIG>");
+    if (a.checkpoint.empty() && (a.checkpoint_every || a.stop_after_portions >= 0)) usage_error("'--checkpoint-every' needs '--checkpoint <FILE>'");
     if (a.dump_scene.empty()) {
         if (a.render.empty()) usage_error("the following required arguments were not provided: --render-config <RENDER_CONFIG>");
         if (a.output.empty()) usage_error("the following required arguments were not provided: --output <OUTPUT>");
@@ -159,6 +173,78 @@ void dump_scene(const host::SceneData& sc, const std::string& path) {
     std::fwrite(sc.prims.data(), sizeof(rrt_prim), sc.prims.size(), f);
     std::fwrite(sc.materials.data(), sizeof(rrt_material), sc.materials.size(), f);
     if (std::fclose(f) != 0) throw std::runtime_error("short write to " + path);
+}
+
+// ---------------------------------------------------------------- checkpoint file
+// Header, then width * height * 3 f32 radiance sums.  A file is taken up only by the render it came from: same scene
+// (a hash of the flattened primitives, materials and camera), image, sampler, depth limits, seed, estimator and arithmetic.
+struct CheckpointHeader {
+    uint32_t magic, version;       // "RRTC", 1
+    uint32_t width, height, sampler_type, spp, x_strata, y_strata, min_depth, max_depth, precision, flags;
+    uint64_t seed, sample_begin, sample_end;
+    uint64_t scene_hash;
+    uint64_t next_sample;          // the sums hold the sample indices [sample_begin, next_sample) of every pixel
+    uint64_t samples, rays, prim_tests, node_tests, nonfinite;  // counters of what was traced so far
+    double kernel_ms;
+};
+const uint32_t kCheckpointMagic = 0x43545252u;  // "RRTC"
+
+uint64_t fnv1a(const void* data, size_t bytes, uint64_t h) {
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+    return h;
+}
+
+CheckpointHeader checkpoint_identity(const host::SceneData& sc, const rrt_render_desc& d) {
+    CheckpointHeader h;
+    std::memset(&h, 0, sizeof(h));
+    h.magic = kCheckpointMagic;
+    h.version = 1;
+    h.width = d.width; h.height = d.height; h.sampler_type = d.sampler_type; h.spp = d.spp;
+    h.x_strata = d.x_strata; h.y_strata = d.y_strata; h.min_depth = d.min_depth; h.max_depth = d.max_depth;
+    h.precision = d.precision; h.flags = d.flags;
+    h.seed = d.seed; h.sample_begin = d.sample_begin; h.sample_end = d.sample_end;
+    uint64_t x = 0xcbf29ce484222325ull;
+    x = fnv1a(&sc.camera, sizeof(sc.camera), x);
+    x = fnv1a(sc.prims.data(), sizeof(rrt_prim) * sc.prims.size(), x);
+    x = fnv1a(sc.materials.data(), sizeof(rrt_material) * sc.materials.size(), x);
+    h.scene_hash = x;
+    h.next_sample = d.sample_begin;
+    return h;
+}
+
+// true: `h` and `sums` hold the file's state.  false: no such file.  Throws on a file of another render or a damaged one.
+bool checkpoint_load(const std::string& path, const CheckpointHeader& want, CheckpointHeader& h, std::vector<float>& sums) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    const bool got = std::fread(&h, sizeof(h), 1, f) == 1;
+    bool same = got && h.magic == want.magic && h.version == want.version;
+    if (same) {
+        CheckpointHeader a = h, b = want;  // everything but the progress must agree
+        a.next_sample = b.next_sample = 0;
+        a.samples = a.rays = a.prim_tests = a.node_tests = a.nonfinite = 0;
+        a.kernel_ms = 0;
+        same = std::memcmp(&a, &b, sizeof(a)) == 0;
+    }
+    if (!same) {
+        std::fclose(f);
+        throw std::runtime_error(path + " is not a checkpoint of this render (another scene, image, sampler, seed or precision); remove it to start over");
+    }
+    const bool whole = std::fread(sums.data(), sizeof(float), sums.size(), f) == sums.size() && std::fgetc(f) == EOF;
+    std::fclose(f);
+    if (!whole || h.next_sample < h.sample_begin || h.next_sample > h.sample_end)
+        throw std::runtime_error(path + " is damaged (wrong length or progress); remove it to start over");
+    return true;
+}
+
+// Written beside the file and renamed over it: an interrupted write leaves the previous state.
+void checkpoint_save(const std::string& path, const CheckpointHeader& h, const std::vector<float>& sums) {
+    const std::string tmp = path + ".part";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write " + tmp);
+    const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 && std::fwrite(sums.data(), sizeof(float), sums.size(), f) == sums.size();
+    if (std::fclose(f) != 0 || !ok) throw std::runtime_error("short write to " + tmp);
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp + " to " + path);
 }
 
 #define RRT_CALL(expr)                                                         \
@@ -190,54 +276,112 @@ int run(const Args& a) {
     const auto t_render = std::chrono::steady_clock::now();
 
     // One host thread per GPU, each with its own scene and backend handle (handles are not shared
-    // between threads).  GPU g traces sample indices [begin + g n / G, begin + (g + 1) n / G) of every
+    // between threads).  Of a portion [lo, hi) of sample indices GPU g traces [lo + g n / G, lo + (g + 1) n / G) of every
     // pixel with the same seed -- the stratified permutations are keyed on (seed, pixel, dimension), so
-    // the shards together visit each stratum once -- into a host accumulator of its own.
-    const uint64_t s_begin = rs.render.sample_begin, s_count = rs.render.sample_end - rs.render.sample_begin;
-    std::vector<std::vector<float>> sums(n_dev);
-    std::vector<rrt_stats> part(n_dev);
-    std::vector<std::string> errors(n_dev);
-    auto worker = [&](size_t g) {
-        rrt_render_desc d = rs.render;
-        d.sample_begin = s_begin + s_count * g / n_dev;
-        d.sample_end = s_begin + s_count * (g + 1) / n_dev;
-        std::memset(&part[g], 0, sizeof(rrt_stats));
-        if (d.sample_end == d.sample_begin) return;  // more GPUs than samples
-        sums[g].assign(n_values, 0.f);
-        rrt_scene_desc desc = sc.desc();
+    // the shards together visit each stratum once -- into a host accumulator of its own.  Without --checkpoint the
+    // whole render is one portion.
+    struct DeviceContext {
         rrt_scene* scene = nullptr;
         rrt_backend* backend = nullptr;
-        if (rrt_scene_create(&desc, &scene) != RRT_OK || rrt_backend_create("hip", devices[g], &backend) != RRT_OK ||
-            rrt_render_accumulate(backend, scene, &d, sums[g].data(), &part[g]) != RRT_OK)
-            errors[g] = rrt_last_error();  // thread-local in the library
-        rrt_backend_destroy(backend);
-        rrt_scene_destroy(scene);
+        std::vector<float> sums;
+        rrt_stats part;
+        std::string error;
     };
-    if (n_dev == 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> threads;
-        for (size_t g = 0; g < n_dev; ++g) threads.emplace_back(worker, g);
-        for (std::thread& t : threads) t.join();
-    }
-    for (size_t g = 0; g < n_dev; ++g)
-        if (!errors[g].empty()) throw std::runtime_error("GPU " + std::to_string(devices[g]) + ": " + errors[g]);
+    std::vector<DeviceContext> ctx(n_dev);
+    auto worker = [&](size_t g, uint64_t lo, uint64_t hi) {
+        DeviceContext& c = ctx[g];
+        rrt_render_desc d = rs.render;
+        const uint64_t n = hi - lo;
+        d.sample_begin = lo + n * g / n_dev;
+        d.sample_end = lo + n * (g + 1) / n_dev;
+        std::memset(&c.part, 0, sizeof(rrt_stats));
+        if (d.sample_end == d.sample_begin) return;  // more GPUs than samples
+        c.sums.assign(n_values, 0.f);
+        if (!c.scene) {
+            rrt_scene_desc desc = sc.desc();
+            if (rrt_scene_create(&desc, &c.scene) != RRT_OK || rrt_backend_create("hip", devices[g], &c.backend) != RRT_OK) {
+                c.error = rrt_last_error();  // thread-local in the library
+                return;
+            }
+        }
+        if (rrt_render_accumulate(c.backend, c.scene, &d, c.sums.data(), &c.part) != RRT_OK) c.error = rrt_last_error();
+    };
+    auto release = [&]() {
+        for (DeviceContext& c : ctx) {
+            rrt_backend_destroy(c.backend);
+            rrt_scene_destroy(c.scene);
+            c.backend = nullptr;
+            c.scene = nullptr;
+        }
+    };
     std::vector<float> total(n_values, 0.f);
-    for (size_t g = 0; g < n_dev; ++g) {
-        if (sums[g].empty()) continue;
-        for (size_t i = 0; i < n_values; ++i) total[i] += sums[g][i];
-        stats.samples += part[g].samples;
-        stats.rays += part[g].rays;
-        stats.prim_tests += part[g].prim_tests;
-        stats.node_tests += part[g].node_tests;
-        stats.nonfinite += part[g].nonfinite;
-        stats.exact_redos += part[g].exact_redos;
-        stats.stack_overflows += part[g].stack_overflows;
-        stats.kernel_ms = std::max(stats.kernel_ms, part[g].kernel_ms);
-        stats.tree_build_ms = std::max(stats.tree_build_ms, part[g].tree_build_ms);
-        stats.accel_used = part[g].accel_used;  // (the same on every GPU: one scene, one description)
-        stats.pipeline_used = part[g].pipeline_used;
-        stats.tree_depth = part[g].tree_depth;
+    CheckpointHeader progress = checkpoint_identity(sc, rs.render);
+    if (!a.checkpoint.empty()) {
+        CheckpointHeader found;
+        if (checkpoint_load(a.checkpoint, progress, found, total)) {
+            progress = found;
+            std::fprintf(stderr, "resuming %s at sample index %llu of [%llu, %llu)\n", a.checkpoint.c_str(), (unsigned long long)progress.next_sample,
+                         (unsigned long long)progress.sample_begin, (unsigned long long)progress.sample_end);
+        }
+    }
+    const uint64_t s_end = rs.render.sample_end, s_count = s_end - rs.render.sample_begin;
+    uint64_t portion = s_count ? s_count : 1;
+    if (!a.checkpoint.empty()) portion = a.checkpoint_every ? a.checkpoint_every : std::max<uint64_t>(1, (s_count + 7) / 8);
+    long portions_done = 0;
+    bool interrupted = false;
+    for (uint64_t lo = progress.next_sample; lo < s_end; lo += portion) {
+        if (a.stop_after_portions >= 0 && portions_done >= a.stop_after_portions) {
+            interrupted = true;
+            break;
+        }
+        const uint64_t hi = std::min(s_end, lo + portion);
+        if (n_dev == 1) {
+            worker(0, lo, hi);
+        } else {
+            std::vector<std::thread> threads;
+            for (size_t g = 0; g < n_dev; ++g) threads.emplace_back(worker, g, lo, hi);
+            for (std::thread& t : threads) t.join();
+        }
+        for (size_t g = 0; g < n_dev; ++g)
+            if (!ctx[g].error.empty()) {
+                const std::string what = "GPU " + std::to_string(devices[g]) + ": " + ctx[g].error;
+                release();
+                throw std::runtime_error(what);
+            }
+        double kernel_ms = 0;
+        for (size_t g = 0; g < n_dev; ++g) {
+            const DeviceContext& c = ctx[g];
+            if (c.part.samples == 0 && c.part.rays == 0 && c.part.kernel_ms == 0) continue;  // no share of this portion
+            for (size_t i = 0; i < n_values; ++i) total[i] += c.sums[i];
+            progress.samples += c.part.samples;
+            progress.rays += c.part.rays;
+            progress.prim_tests += c.part.prim_tests;
+            progress.node_tests += c.part.node_tests;
+            progress.nonfinite += c.part.nonfinite;
+            stats.exact_redos += c.part.exact_redos;
+            stats.stack_overflows += c.part.stack_overflows;
+            kernel_ms = std::max(kernel_ms, c.part.kernel_ms);
+            stats.tree_build_ms = std::max(stats.tree_build_ms, c.part.tree_build_ms);
+            stats.accel_used = c.part.accel_used;  // (the same on every GPU: one scene, one description)
+            stats.pipeline_used = c.part.pipeline_used;
+            stats.tree_depth = c.part.tree_depth;
+        }
+        progress.kernel_ms += kernel_ms;
+        progress.next_sample = hi;
+        portions_done += 1;
+        if (!a.checkpoint.empty()) checkpoint_save(a.checkpoint, progress, total);
+    }
+    release();
+    stats.samples = progress.samples;
+    stats.rays = progress.rays;
+    stats.prim_tests = progress.prim_tests;
+    stats.node_tests = progress.node_tests;
+    stats.nonfinite = progress.nonfinite;
+    stats.kernel_ms = progress.kernel_ms;
+    if (interrupted) {
+        std::fprintf(stderr, "stopped after %ld portion(s) at sample index %llu; state in %s\n", portions_done,
+                     (unsigned long long)progress.next_sample, a.checkpoint.c_str());
+        return 3;
     }
     {   // mean -> tone map -> gamma -> white balance -> u8 on the first GPU; the divisor is samples_per_pixel
         // even where RandomSampler traced one sample more (src/sampler.rs:48-55, src/renderer.rs:128)

@@ -182,3 +182,47 @@ def test_cli_accel_names(tmp_path):
     r = subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(tmp_path / "x.png"), "--accel", "octree"],
                        capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert r.returncode == 2
+
+
+def test_cli_checkpoint_and_resume(tmp_path):
+    """`rrt --checkpoint FILE`: a run that stops after some portions of the sample indices leaves its radiance sums and
+    its place in FILE; the next run takes them up, traces only the rest, and writes the image an uninterrupted run writes
+    (same samples, same ray count; sums differ by float addition order before the 8-bit quantisation).  A checkpoint of
+    another render is refused, not overwritten.  (The reference writes its image once, at the end: src/main.rs:49.)"""
+    from PIL import Image
+    scene = os.path.join(ROOT, "configs", "cornell_box", "scene.toml")
+    rc_path = tmp_path / "r.toml"
+    rc_path.write_text(RENDER.format(sampler="Stratified", strata="x_strata = 8\ny_strata = 8", wb=""))
+    ck = tmp_path / "state.rrtc"
+
+    def run(out, stats, *extra):
+        return subprocess.run([RRT, "-s", scene, "-r", str(rc_path), "-o", str(out), "--stats-json", str(stats), *extra],
+                              capture_output=True, text=True, timeout=120, cwd=ROOT)
+
+    r = run(tmp_path / "whole.png", tmp_path / "whole.json")
+    assert r.returncode == 0, r.stderr
+    whole = np.asarray(Image.open(tmp_path / "whole.png").convert("RGB")).astype(int)
+    js_whole = json.load(open(tmp_path / "whole.json"))
+
+    # 64 sample indices in portions of 10: stop after three portions, as an interrupted run would
+    r = run(tmp_path / "a.png", tmp_path / "a.json", "--checkpoint", str(ck), "--checkpoint-every", "10", "--stop-after-portions", "3")
+    assert r.returncode == 3 and "sample index 30" in r.stderr and ck.exists() and not (tmp_path / "a.png").exists()
+    assert ck.stat().st_size > 96 * 64 * 3 * 4 and not (tmp_path / "state.rrtc.part").exists()
+    # a different seed is another render: refused, the file stays as it is
+    before = ck.read_bytes()
+    r = run(tmp_path / "x.png", tmp_path / "x.json", "--checkpoint", str(ck), "--seed", "8")
+    assert r.returncode == 101 and "not a checkpoint of this render" in r.stderr and ck.read_bytes() == before
+    # the rest: four portions (30..64)
+    r = run(tmp_path / "b.png", tmp_path / "b.json", "--checkpoint", str(ck), "--checkpoint-every", "10")
+    assert r.returncode == 0 and "resuming" in r.stderr and "sample index 30" in r.stderr, r.stderr
+    got = np.asarray(Image.open(tmp_path / "b.png").convert("RGB")).astype(int)
+    js = json.load(open(tmp_path / "b.json"))
+    assert js["samples"] == js_whole["samples"] == 96 * 64 * 64 and js["rays"] == js_whole["rays"]
+    assert np.abs(got - whole).max() <= 1 and np.mean(got != whole) < 0.01
+    # a finished checkpoint: nothing left to trace, the same image again
+    r = run(tmp_path / "c.png", tmp_path / "c.json", "--checkpoint", str(ck))
+    assert r.returncode == 0 and np.array_equal(np.asarray(Image.open(tmp_path / "c.png").convert("RGB")).astype(int), got)
+    # a damaged file is refused too
+    ck.write_bytes(before[:-4])
+    r = run(tmp_path / "d.png", tmp_path / "d.json", "--checkpoint", str(ck))
+    assert r.returncode == 101 and "damaged" in r.stderr

@@ -198,6 +198,8 @@ def test_cli_argument_errors(tmp_path):
     assert r.returncode == 2 and "--output" in r.stderr
     assert run("-s", scene, "-r", render, "-o", "x.png", "--bogus").returncode == 2
     assert run("--help").returncode == 0 and "--scene-config" in run("--help").stdout
+    assert run("-s", scene, "-r", render, "-o", "x.png", "--checkpoint-every", "4").returncode == 2  # needs --checkpoint
+    assert run("-s", scene, "-r", render, "-o", "x.png", "--checkpoint", "c.bin", "--checkpoint-every", "0").returncode == 2
     # a well-formed call reaches the backend; without a GPU it must fail there, loudly, not fall back
     r = run("--scene-config=" + scene, "--render-config", render, "--output", str(tmp_path / "x.png"))
     import torch
