@@ -693,7 +693,17 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) 
             HIP_TRY(hipMemcpyAsync(dlo.p, lo.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
             HIP_TRY(hipMemcpyAsync(dhi.p, hi.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, be->stream));
             HIP_TRY(hipMemcpyAsync(dsize.p, size.data(), sizeof(float) * n, hipMemcpyHostToDevice, be->stream));
-            HIP_TRY(rrt::gsah_tree((const float*)dlo.p, (const float*)dhi.p, (const float*)dsize.p, n, (rrt::WideNode*)nodes, (int*)slots, be->stream, &depth));
+            hipError_t built = rrt::gsah_tree((const float*)dlo.p, (const float*)dhi.p, (const float*)dsize.p, n, (rrt::WideNode*)nodes, (int*)slots, be->stream, &depth);
+            static const bool debug_fail = getenv("RRT_DEBUG_GSAH_FAIL") != nullptr;  // tests only: take the path below
+            if (debug_fail) built = hipErrorUnknown;
+            if (built == hipErrorOutOfMemory) HIP_TRY(built);
+            if (built != hipSuccess) {
+                // The level-by-level build gives up on a tree thousands of levels deep (ranges that lose one primitive per
+                // cut): the host builder makes the same tree, and the depth check below then replaces it by median cuts.
+                (void)hipGetLastError();
+                if ((rc = host_tree(false)) != RRT_OK) return rc;
+                on_host = true;
+            }
         } else {
             DevBuf dlo, dhi;
             HIP_TRY(dlo.alloc(sizeof(float) * 3 * n));

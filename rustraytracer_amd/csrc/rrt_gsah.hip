@@ -63,7 +63,8 @@ struct GsControl {
     int n_sweep;              // ranges left to the sweep threads
     int n_top;                // nodes made by tasks (marked level by level afterwards)
     int max_level;
-    int error;                // 1: a list overflowed (cannot happen with lists sized for n)
+    int error;                // 1: a list overflowed (cannot happen: the ranges of a level are disjoint, so a level holds at
+                              // most n / (smallest range of the class + 1) tasks of a class, and the lists are that long)
 };
 
 struct GsParams {
@@ -675,7 +676,7 @@ hipError_t gsah_build(const float* d_lo, const float* d_hi, const float* d_size,
     P.cap_big = n / GS_WAVE_MAX + 2;
     P.cap_wave = n / GS_SWEEP_MAX + 2;
     P.cap_sweep = n / 2 + 2;
-    P.cap_top = n / GS_SWEEP_MAX * 2 + 64;
+    P.cap_top = n;  // every task makes one of the tree's n - 1 nodes
     P.cap_chunks = n / GS_CHUNK + P.cap_big + 2;  // every large task ends in at most one chunk that is not full
     void* mem[20] = {};
     auto cleanup = [&]() { for (void* m : mem) (void)hipFree(m); };

@@ -364,3 +364,34 @@ print("fallback ok")
     env = dict(os.environ, RRT_ROOT=ROOT, RRT_DEBUG_MAX_TREE_DEPTH="3")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_the_host_builder_stands_in_when_the_gpu_builder_gives_up(cfg):
+    """The level-by-level GPU build stops at a tree thousands of levels deep; the library then has the host builder make
+    the same tree.  RRT_DEBUG_GSAH_FAIL sends an ordinary mesh down that path: the scan's hits, the host builder's depth."""
+    import subprocess
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["RRT_ROOT"]); sys.path.insert(0, os.path.join(os.environ["RRT_ROOT"], "tests"))
+import numpy as np
+from oracle import oracle_py as O
+from rustraytracer_amd import api, config
+import scenes_util as S
+import test_gpu_lbvh as T
+flat = T.mesh_scene(3000)
+be, sc = api.Backend(0), api.Scene(flat)
+o, d = S.secondary_rays(flat, O, 20000, seed=6)
+lin = be.intersect(sc, o, d, accel=api.ACCEL_LINEAR)
+rc = config.stratified_config(64, 64, 2, 2)
+depth = {}
+for accel in (api.ACCEL_SAH_GPU, api.ACCEL_SAH):
+    got = be.intersect(sc, o, d, accel=accel)
+    assert all(np.array_equal(a, b) for a, b in zip(lin, got)), accel
+    _, st = be.render_accumulate(sc, rc.render_desc(accel=accel))
+    depth[accel] = (st["tree_depth"], st["node_tests"], st["prim_tests"])
+assert depth[api.ACCEL_SAH_GPU] == depth[api.ACCEL_SAH], depth
+print("stand-in ok", depth)
+'''
+    env = dict(os.environ, RRT_ROOT=ROOT, RRT_DEBUG_GSAH_FAIL="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0 and "stand-in ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
