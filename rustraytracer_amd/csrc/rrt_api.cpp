@@ -4,6 +4,7 @@
 // device or fails with an error code.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -16,6 +17,7 @@
 #include <new>
 #include <string>
 #include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/rrt.h"
