@@ -15,7 +15,9 @@
  *     thread-local message for the last failure on the calling thread
  *   - all arithmetic inputs are f64, as in the reference (src/math.rs:4-8);
  *     the device computes in f32 or f64 as rrt_render_desc.precision says
- *   - handles are not thread-safe; one host thread drives one backend
+ *   - a backend handle is not thread-safe: one host thread drives one backend.  A scene handle may be used by
+ *     several host threads at once, each with a backend of its own: what a scene builds on first use on a device
+ *     (its tables, a tree) is built once, under the scene's own lock
  *   - pointers named *_dev_or_host may be device or host memory; the library
  *     asks the HIP runtime which one it was given
  */
@@ -70,7 +72,7 @@ typedef enum rrt_precision { RRT_PRECISION_F32 = 0, RRT_PRECISION_F64 = 1 } rrt_
  * that are not planar are scanned beside the tree), all returning the primitive and t the scan returns:
  *   SAH_GPU  binned surface-area-heuristic tree built top-down ON THE GPU, level by level (one work-group per range,
  *            16 bins along four cut coordinates, ranges of up to 32 primitives by an exact sweep);
- *   SAH      the same tree built by up to 16 host threads (~0.5 s per million primitives): the implementation the GPU
+ *   SAH      the same tree built by up to 16 host threads (~0.2 s per million primitives): the implementation the GPU
  *            builder is checked against (same cuts, same tree);
  *   LBVH     built on the GPU: primitives in Morton order, clustered bottom-up (neighbours whose union has the
  *            smallest box merge first); about a tenth more traversal steps per ray.

@@ -229,6 +229,9 @@ struct rrt_scene {
     std::vector<rrt_prim> prims;
     std::vector<rrt_material> materials;
     std::map<int, DeviceScene*> dev;
+    // Guards `dev` and the first-use builds (device tables, trees): host threads may share one scene, each with a
+    // backend of its own; what they build on first use is built once, by whoever comes first.
+    std::mutex mu;
 };
 
 struct rrt_backend {
@@ -443,6 +446,7 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view, rrt
 // Device copy of a scene for the backend's GPU, built on first use.
 int device_scene(rrt_backend* be, const rrt_scene* sc_const, DeviceScene** out) {
     rrt_scene* sc = const_cast<rrt_scene*>(sc_const);
+    std::lock_guard<std::mutex> lock(sc->mu);
     auto it = sc->dev.find(be->device);
     if (it != sc->dev.end()) {
         *out = it->second;
@@ -527,7 +531,9 @@ rrt::SceneView<double> with_tree(const rrt_backend* be, const DeviceScene* ds, c
 // kTreeStackEntries: a tree deeper than that (the cost function can peel primitives off one by one on adversarial
 // input; the clustering makes one level per round) is rebuilt with median cuts, which bound the depth by log2 n.
 const int kTreeStackEntries = rrt::BVH_STACK_ENTRIES;
-int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind) {
+int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind, bool* built_now) {
+    std::lock_guard<std::mutex> lock(const_cast<rrt_scene*>(sc)->mu);
+    if (built_now) *built_now = !ds->tree[kind].built;
     if (ds->tree[kind].built) return RRT_OK;
     const auto t_begin = std::chrono::steady_clock::now();
     std::vector<int32_t> bounded, unbounded;  // scan-order indices
@@ -776,8 +782,8 @@ const uint32_t kAccelOfKind[3] = {RRT_ACCEL_LBVH, RRT_ACCEL_SAH, RRT_ACCEL_SAH_G
 // *kind = the tree the call walks (-1: none); *built_now = whether this call built it.
 int resolve_accel(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, uint32_t accel, int* kind, bool* built_now = nullptr) {
     *kind = tree_kind(sc, accel);
-    if (built_now) *built_now = *kind >= 0 && !ds->tree[*kind].built;
-    return *kind >= 0 ? ensure_bvh(be, sc, ds, *kind) : RRT_OK;
+    if (built_now) *built_now = false;
+    return *kind >= 0 ? ensure_bvh(be, sc, ds, *kind, built_now) : RRT_OK;
 }
 
 // How a caller's buffer is used.  Kernels write in place only into plain device memory of the backend's own GPU:

@@ -395,3 +395,33 @@ print("stand-in ok", depth)
     env = dict(os.environ, RRT_ROOT=ROOT, RRT_DEBUG_GSAH_FAIL="1")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0 and "stand-in ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_two_host_threads_share_one_scene(gpu, O):
+    """Two host threads, each with a backend of its own, use ONE scene at once and ask for different trees on its first
+    use: the device tables and each tree are built once, by whoever comes first, and both get the scan's hits."""
+    import threading
+    api, be = gpu
+    flat = mesh_scene(20000, seed=9)
+    o, d = S.secondary_rays(flat, O, 20000, seed=8)
+    lin = be.intersect(api.Scene(flat), o, d, accel=api.ACCEL_LINEAR)
+    for _ in range(3):
+        sc = api.Scene(flat)  # fresh: nothing resident, nothing built
+        out, err = {}, []
+
+        def work(name, accel):
+            try:
+                mine = api.Backend(0)
+                out[name] = mine.intersect(sc, o, d, accel=accel)
+            except Exception as e:  # noqa: BLE001 -- reported by the assertion below
+                err.append((name, e))
+
+        threads = [threading.Thread(target=work, args=(n, a)) for n, a in
+                   (("a", api.ACCEL_SAH_GPU), ("b", api.ACCEL_LBVH), ("c", api.ACCEL_SAH_GPU), ("d", api.ACCEL_SAH))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not err, err
+        for name in "abcd":
+            assert _same(lin, out[name]), name
