@@ -111,8 +111,10 @@ public:
         top_threads_ = std::max(1, threads);
         const int grain = std::max(4096, n_ / 64);
         std::vector<Job> jobs;
+        at_top_ = true;  // (only this thread is at work: large ranges may use all the threads and the shared scratch)
         if (n_ <= grain) jobs.push_back({0, 0, n_});
         else expand(nodes, 0, 0, n_, grain, &jobs);
+        at_top_ = false;
         std::vector<std::vector<BvhNode>> local(jobs.size());
         std::atomic<size_t> next{0};
         auto work = [&]() {
@@ -211,6 +213,7 @@ private:
     std::vector<int32_t> temp_;  // scratch of the top-of-tree partition
     float coord(size_t p, int a) const { return a < 3 ? 0.5f * (lo_[3 * p + a] + hi_[3 * p + a]) : size_[p]; }
     int top_threads_ = 1;
+    bool at_top_ = false;  // the calling thread is splitting the top of the tree; the jobs have not started
     bool median_ = false;
     struct Extent {
         float lo[AXES], hi[AXES];
@@ -333,7 +336,10 @@ private:
         if (count <= SWEEP_MAX) return partition_sweep(first, count, bl, br);
         Extent ext;
         ext.clear();
-        const int chunks = count >= 65536 ? top_threads_ : 1;  // only the ranges at the top of the tree are that large
+        // Large ranges at the top of the tree are cut with all the threads.  Never inside a job: the jobs run side by side
+        // (above 64 x 65536 primitives their ranges are this large too) and the scratch of the gather is one per builder.
+        // (The tree does not depend on which way a range was partitioned: nothing below reads the order inside a part.)
+        const int chunks = (count >= 65536 && at_top_) ? top_threads_ : 1;
         std::vector<Extent> ext_part((size_t)chunks);
         run_chunks(first, count, chunks, [&](int c, int f, int n) { ext_part[(size_t)c].clear(); extent(f, n, ext_part[(size_t)c]); });
         for (const Extent& e : ext_part)

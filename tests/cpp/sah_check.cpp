@@ -176,7 +176,17 @@ static void run_median() {
     CHECK(depth_of(deep) > 2 * limit, "the onion was meant to make a deep tree (%d levels)", depth_of(deep));
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc == 3 && std::strcmp(argv[1], "big") == 0) {  // sah_check big N: one large input (minutes; not part of the test run)
+        const int n = std::atoi(argv[2]);
+        Input in = random_boxes(n, 7, 30.f);
+        std::vector<BvhNode> a;
+        std::vector<int32_t> oa;
+        rrt::SahBuilder(in.lo.data(), in.hi.data(), in.n(), 1).build(a, oa, 16);
+        check_tree("big", in, 1, a, oa);
+        std::printf("big %d: %zu nodes, %d levels, %d failures\n", n, a.size(), depth_of(a), failures);
+        return failures ? 1 : 0;
+    }
     run_median();
     for (int leaf_max : {1, 2, 4}) {
         run("two", random_boxes(2, 1, 1.f), leaf_max);
@@ -185,6 +195,15 @@ int main() {
         run("random 300000", random_boxes(300000, 4, 10.f), leaf_max);
         run("same centre 5000", random_boxes(5000, 5, 0.f), leaf_max);
         run("grid 200x200x2", grid_cells(200), leaf_max);
+    }
+    {   // more than 64 x 65536 primitives: the jobs' own ranges are large enough for the many-thread partition of the top
+        // of the tree, which they must not use (one scratch array per builder)
+        Input in = random_boxes(4300000, 9, 30.f);
+        std::vector<BvhNode> a;
+        std::vector<int32_t> oa;
+        rrt::SahBuilder(in.lo.data(), in.hi.data(), in.n(), 1).build(a, oa, 8);
+        check_tree("random 4300000", in, 1, a, oa);
+        std::printf("%-22s n %7d: %7zu nodes, %d levels\n", "random 4300000", in.n(), a.size(), depth_of(a));
     }
     {   // every box identical: no cut is better than another, the build must still end
         Input in;
