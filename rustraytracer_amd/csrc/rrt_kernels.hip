@@ -166,7 +166,7 @@ render_fused(SceneView<R> sv, RenderParams rp, LightView<R> lights, SceneView<do
             if (g >= 0) {
                 const ShadeRec<R> sh = LDS_TABLES ? s_shade[g] : sv.shade[g];
                 m = LDS_TABLES ? s_mats[sh.object_id] : sv.mats[sh.object_id];
-                mode = process_hit<R>(rp, path, sh, m, t, acc, n, bad, counted, !(NEE && lights_sampled));
+                mode = process_hit<R, NEE>(rp, path, sh, m, t, acc, n, bad, counted, !(NEE && lights_sampled));
             }
 #endif
             if (NEE) {

@@ -93,10 +93,22 @@ enum : int { MODE_NEW = 0 };
 // fetches them: from HBM, or from the copy a kernel keeps in LDS for a small scene).
 // count_emission = false: the emitter still ends the path but adds nothing (next-event estimation has already
 // counted the light from the previous vertex).
-template <typename R>
+// JUDGED_POINT: the vertex is computed with every product and sum rounded, which makes it, bit for bit, the point the
+// primitive test judged (plane_point).  Shadow rays leave their vertex towards ONE point, so on a finely tessellated
+// surface a whole band of them (the terminator as the light sees it) grazes the vertex's own and the neighbouring
+// triangles; with a fused multiply-add here -- the compiler's choice, and not the same choice in every kernel -- an f32
+// render of the million-triangle scene left the f64 render's paths in three times as many pixels.  The kernels of the
+// reference's estimator keep the fused form (three instructions less per hit).
+template <typename R, bool JUDGED_POINT = false>
 RRT_DEV int process_hit(const RenderParams& rp, Path<R>& p, const ShadeRec<R>& sh, const MatRec<R>& m, R t, V3<R>& acc,
                         V3<R>& n, bool& bad, int& counted, bool count_emission = true) {
-    V3<R> P = mk<R>(p.o.x + t * p.d.x, p.o.y + t * p.d.y, p.o.z + t * p.d.z);
+    V3<R> P;
+    if constexpr (JUDGED_POINT) {
+#pragma clang fp contract(off)
+        P = mk<R>(p.o.x + t * p.d.x, p.o.y + t * p.d.y, p.o.z + t * p.d.z);
+    } else {
+        P = mk<R>(p.o.x + t * p.d.x, p.o.y + t * p.d.y, p.o.z + t * p.d.z);
+    }
     n = mk<R>(sh.nx, sh.ny, sh.nz);
     if (sh.type == PRIM_SPHERE) {  // (point - center) / radius, src/shapes/sphere.rs:87
         R inv_r = Num<R>::rcp(sh.w);
@@ -245,6 +257,7 @@ RRT_DEV bool scatter(Path<R>& p, int mode, V3<R> n, const MatRec<R>& m, R u, R v
 // sides, as Material::emission has no facing test, src/material.rs:52-54).
 template <typename R>
 RRT_DEV bool sample_light(const LightView<R>& lv, V3<R> x, R pick, R u, R v, V3<R>& wi, R& dist, V3<R>& le_w, int& prim) {
+#pragma clang fp contract(off)  // (the same point and direction in every kernel that samples the lights)
     if (lv.n <= 0) return false;
     int lo = 0, hi = lv.n - 1;  // first light whose cumulative probability exceeds pick (the last if none)
     while (lo < hi) {

@@ -424,7 +424,7 @@ wf_shade(SceneView<R> sv, RenderParams rp, WfParams<R> wp, LightView<R> lights, 
             V3<R> acc = mk<R>(0, 0, 0);
             const ShadeRec<R> sh = sv.shade[g];
             m = sv.mats[sh.object_id];
-            mode = process_hit<R>(rp, path, sh, m, t_hit, acc, n, bad, counted, !(NEE && lights_sampled));
+            mode = process_hit<R, NEE>(rp, path, sh, m, t_hit, acc, n, bad, counted, !(NEE && lights_sampled));
             // only an emitter adds radiance, and it ends the path: at most one add per sample
             if (acc.x != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 0], (float)acc.x);
             if (acc.y != R(0)) atomicAdd(&rp.accum[3 * (size_t)pixel + 1], (float)acc.y);
@@ -641,6 +641,11 @@ hipError_t wf_launch_init(const RenderParams& rp, const WfParams<R>& wp, hipStre
 namespace {
 // persistent waves through the tree (f32: the product path)
 void launch_tree_walk(const SceneView<float>& sv, const WfParams<float>& wp, int parity, int sh, int n_cu, uint32_t grid_x, hipStream_t stream) {
+    static const bool plain = getenv("RRT_DEBUG_WF_PLAIN_WALK") != nullptr;  // experiments: one ray per lane from start to end
+    if (plain) {
+        hipLaunchKernelGGL((wf_closest_hit<float, true>), dim3(grid_x), dim3(WF_HIT_BLOCK), 0, stream, sv, wp, parity, sh);
+        return;
+    }
     // as many blocks as the device really holds at once (8 per CU with the kernel's registers and LDS; a block more
     // than fits would run after all the others, alone), never more than there are rays
     static const int per_cu = [] {
