@@ -248,7 +248,11 @@ int rrt_intersect_static(rrt_backend* backend, const rrt_scene* scene, uint32_t 
  * MonteCarloPathTracer::trace (src/tracers/mcpt.rs:20-43) inside, for sample
  * indices [sample_begin, sample_end) of every pixel.  ADDS the radiance of the
  * traced samples to rgb_sum (width*height*3 floats, row-major, RGB), which the
- * caller owns and zeroes; stats may be NULL. */
+ * caller owns and zeroes; stats may be NULL.
+ * The sums are f32 (the reference adds in f64): with up to 2^20 samples per pixel in one sum the worst pixel is
+ * within 5e-5 of the f64 sum (2^16: 3e-6), far inside the 8-bit output; at 2^24 the error reaches 7e-4 (fused) to
+ * 2e-2 (wavefront, which adds every sample by itself).  A render with more samples per pixel than that belongs in
+ * several calls over parts of the sample range, each into a sum of its own, added in f64 by the caller. */
 int rrt_render_accumulate(rrt_backend* backend, const rrt_scene* scene, const rrt_render_desc* desc,
                           float* rgb_sum_dev_or_host, rrt_stats* stats);
 
