@@ -5,4 +5,4 @@ cd "$(dirname "$0")/.."
 NAME=$1; shift
 mkdir -p build_variants
 cd rustraytracer_amd/csrc
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -munsafe-fp-atomics -fno-gpu-rdc -fno-slp-vectorize -Wall -Wno-unused-function "$@" -x hip rrt_api.cpp rrt_kernels.hip rrt_lbvh.hip rrt_ploc.hip rrt_gsah.hip rrt_wavefront.hip -o ../../build_variants/librrt_$NAME.so
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -munsafe-fp-atomics -fno-gpu-rdc -fno-slp-vectorize -ffp-contract=on -Wall -Wno-unused-function "$@" -x hip rrt_api.cpp rrt_kernels.hip rrt_lbvh.hip rrt_ploc.hip rrt_gsah.hip rrt_wavefront.hip -o ../../build_variants/librrt_$NAME.so

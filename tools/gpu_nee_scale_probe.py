@@ -1,8 +1,7 @@
 """The two pipelines against each other on the million-triangle scene (device only), with and without next-event
-estimation (shadow rays through the shadow queue and the persistent tree kernel).  In f64 they must agree ray for ray and
-pixel for pixel.  In f32 the two kernels round a few expressions differently (the compiler fuses multiply-adds kernel by
-kernel), which decides a grazing ray on this finely tessellated scene differently now and then: ray counts must agree to
-1e-6, and at most half a per cent of the pixels may differ by more than 1e-4."""
+estimation (shadow rays through the shadow queue and the persistent tree kernel): they must agree ray for ray and pixel
+for pixel (to float summation order) in both precisions.  (In f32 that holds because the library is built with
+-ffp-contract=on: every kernel then rounds the same expressions the same way.)"""
 import os
 import sys
 
@@ -31,10 +30,7 @@ for prec, w, h, side, flags in ((api.PRECISION_F32, 480, 270, 4, 0), (api.PRECIS
     rel = np.abs(a[0] - b[0]) / (np.abs(a[0]) + 1e-3)
     above = int(np.any(rel > 1e-4, axis=-1).sum())
     rays_rel = abs(a[1]["rays"] - b[1]["rays"]) / a[1]["rays"]
-    if prec == api.PRECISION_F64:
-        ok = rays_rel == 0 and int(np.any(rel > 2e-6, axis=-1).sum()) == 0
-    else:
-        ok = rays_rel <= 1e-6 and above <= 0.005 * w * h
+    ok = rays_rel == 0 and int(np.any(rel > (2e-6 if prec == api.PRECISION_F64 else 2e-5), axis=-1).sum()) == 0
     ok = ok and a[1]["nonfinite"] == 0 and b[1]["nonfinite"] == 0 and a[1]["stack_overflows"] == 0 and b[1]["stack_overflows"] == 0
     print("  ray counts differ by %.1e, pixels above 1e-4: %d of %d -> %s" % (rays_rel, above, w * h, "ok" if ok else "NOT ok"), flush=True)
     bad += 0 if ok else 1
