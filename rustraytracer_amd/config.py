@@ -31,6 +31,25 @@ class ConfigError(ValueError):
     """A config the reference would reject (serde error, unwrap/expect/panic)."""
 
 
+def _as_config_error(what):
+    """Decorator: whatever a loader trips over in a malformed file (a missing key, a short buffer, bytes that are not
+    UTF-8, a count no file could hold) leaves it as ConfigError -- one kind of failure, as every such input is one panic
+    in the reference."""
+    import functools
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def inner(path, *a, **kw):
+            try:
+                return fn(path, *a, **kw)
+            except ConfigError:
+                raise
+            except (KeyError, IndexError, ValueError, TypeError, OverflowError, MemoryError, OSError, UnicodeError, AttributeError) as e:
+                raise ConfigError(f"{what} {path}: {type(e).__name__}: {e}") from e
+        return inner
+    return wrap
+
+
 # ----------------------------------------------------------------------------- math.rs
 def _vec3(t, what):
     try:
@@ -86,6 +105,7 @@ _PLY_SCALAR = {
 }
 
 
+@_as_config_error("mesh")
 def load_ply(path):
     """PlyMeshLoader::load (src/shapes/utils.rs:16-82).
 
@@ -114,6 +134,9 @@ def load_ply(path):
                 fmt = tok[1]
             elif tok[0] == "element":
                 elements.append([tok[1], int(tok[2]), []])
+                # (every record takes at least a byte: a count beyond the file's size is a lie, not a reason to allocate)
+                if not 0 <= elements[-1][1] <= os.path.getsize(path):
+                    raise ConfigError(f"{path}: element {tok[1]} claims {tok[2]} records in a file of {os.path.getsize(path)} bytes")
             elif tok[0] == "property":
                 if tok[1] == "list":
                     elements[-1][2].append(("list", tok[4], tok[2], tok[3]))
@@ -412,6 +435,7 @@ def scene_from_dict(cfg, base_dirs=()):
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@_as_config_error("scene")
 def load_scene(path, base_dirs=None):
     """Parse a scene TOML (src/main.rs:45-47).  Mesh paths are resolved like the
     reference does (relative to the working directory) and then against
@@ -491,6 +515,7 @@ class RenderConfig:
         return p
 
 
+@_as_config_error("render config")
 def load_render_config(path):
     with open(path, "rb") as f:
         return RenderConfig(_toml.load(f))

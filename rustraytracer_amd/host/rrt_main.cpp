@@ -170,8 +170,9 @@ void dump_scene(const host::SceneData& sc, const std::string& path) {
     const uint32_t head[4] = {0x53545252u /* "RRTS" */, (uint32_t)sc.prims.size(), (uint32_t)sc.materials.size(), 0};
     std::fwrite(head, sizeof(head), 1, f);
     std::fwrite(&sc.camera, sizeof(sc.camera), 1, f);
-    std::fwrite(sc.prims.data(), sizeof(rrt_prim), sc.prims.size(), f);
-    std::fwrite(sc.materials.data(), sizeof(rrt_material), sc.materials.size(), f);
+    // (an empty scene has no array to write: fwrite's pointer must not be null even for a count of zero)
+    if (!sc.prims.empty()) std::fwrite(sc.prims.data(), sizeof(rrt_prim), sc.prims.size(), f);
+    if (!sc.materials.empty()) std::fwrite(sc.materials.data(), sizeof(rrt_material), sc.materials.size(), f);
     if (std::fclose(f) != 0) throw std::runtime_error("short write to " + path);
 }
 

@@ -107,3 +107,32 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_abi.PostDesc) == 40
     assert C.sizeof(_abi.Stats) == 8 * 4 + 40 + 8 + 16 + 16 + 8 + 16
     assert _abi.PRIM_DTYPE.itemsize == 112 and _abi.MATERIAL_DTYPE.itemsize == 40
+
+
+def test_malformed_files_fail_one_way(tmp_path, cfg, monkeypatch):
+    """Whatever a loader trips over in a damaged file, it raises ConfigError (every such input is one panic in the
+    reference): bytes that are not UTF-8, a mesh cut off in the middle, a property line cut short, an element count no
+    file could hold."""
+    import shutil
+    shutil.copytree(os.path.join(ROOT, "configs", "cornell_box"), tmp_path / "configs" / "cornell_box")
+    monkeypatch.chdir(tmp_path)  # (mesh paths resolve against the working directory first, as in the reference)
+    scene = tmp_path / "configs" / "cornell_box" / "scene.toml"
+    ply = tmp_path / "configs" / "cornell_box" / "cornell_box_0000_m000.ply"
+    good_scene, good_ply = scene.read_bytes(), ply.read_bytes()
+    base = (str(tmp_path), str(tmp_path / "configs" / "cornell_box"))
+    assert cfg.load_scene(str(scene), base_dirs=base).n_prims == 18
+    for damaged in (good_scene[:300] + b"\xe8\xff" + good_scene[300:], good_scene[: len(good_scene) // 2], good_scene.replace(b"Mesh", b"Mash", 1)):
+        scene.write_bytes(damaged)
+        with pytest.raises(cfg.ConfigError):
+            cfg.load_scene(str(scene), base_dirs=base)
+    scene.write_bytes(good_scene)
+    head_end = good_ply.index(b"end_header")
+    for damaged in (good_ply[: head_end + 40], good_ply.replace(b"property float x", b"property float", 1),
+                    good_ply.replace(b"element vertex ", b"element vertex 99999999", 1), good_ply.replace(b"float", b"\x02loat", 1)):
+        ply.write_bytes(damaged)
+        with pytest.raises(cfg.ConfigError):
+            cfg.load_scene(str(scene), base_dirs=base)
+    render = tmp_path / "r.toml"
+    render.write_bytes(b"[tracer]\ntype = \"mcpt\"\nmin_depth = \xff\n")
+    with pytest.raises(cfg.ConfigError):
+        cfg.load_render_config(str(render))
