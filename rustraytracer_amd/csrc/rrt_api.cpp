@@ -249,6 +249,28 @@ struct rrt_backend {
 
 namespace {
 
+// fn(thread, begin, end) over [0, count) in contiguous shares on up to 16 host threads (one for small counts); a thread
+// that cannot be had (a container's pid limit) leaves its share to the calling thread.  Nothing thrown inside fn may
+// escape a thread: the loops run through it allocate nothing.
+int share_threads(size_t count) {
+    return count < 20000 ? 1 : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+void run_in_shares(size_t count, int n_threads, const std::function<void(int, size_t, size_t)>& fn) {
+    std::vector<std::thread> pool;
+    const size_t per = (count + (size_t)n_threads - 1) / (size_t)n_threads;
+    int started = 1;
+    try {
+        for (; started < n_threads; ++started) {
+            const size_t b = std::min(count, per * (size_t)started), e = std::min(count, b + per);
+            pool.emplace_back(fn, started, b, e);
+        }
+    } catch (const std::system_error&) {
+    }
+    fn(0, 0, std::min(count, per));
+    for (std::thread& t : pool) t.join();
+    if (started < n_threads) fn(started, std::min(count, per * (size_t)started), count);  // what the missing threads would have done
+}
+
 template <typename T>
 int upload(DeviceScene* ds, const std::vector<T>& host, const T** out, hipStream_t stream) {
     *out = nullptr;
@@ -353,12 +375,20 @@ template <typename R>
 int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view, rrt::LightView<R>& lview,
               const std::vector<rrt::PrimRec<double>>& prims, const std::vector<rrt::ShadeRec<double>>& shade,
               const std::vector<rrt::MatRec<double>>& mats, hipStream_t stream) {
+    const auto t_view = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (getenv("RRT_DEBUG_BUILD_TIMES")) fprintf(stderr, "[rrt]   fill_view<%zu>: %s at %.1f ms\n", sizeof(R), what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_view).count()); };
     std::vector<rrt::PrimRec<R>> p(prims.size());
     std::vector<rrt::ShadeRec<R>> s(shade.size());
     std::vector<rrt::MatRec<R>> m(mats.size());
-    for (size_t i = 0; i < prims.size(); ++i) p[i] = narrow<R>(prims[i]);
-    for (size_t i = 0; i < shade.size(); ++i) s[i] = narrow<R>(shade[i]);
+    const int n_threads = share_threads(prims.size());
+    run_in_shares(prims.size(), n_threads, [&](int, size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            p[i] = narrow<R>(prims[i]);
+            s[i] = narrow<R>(shade[i]);
+        }
+    });
     for (size_t i = 0; i < mats.size(); ++i) m[i] = narrow<R>(mats[i]);
+    lap("narrowed");
     std::memset(&view, 0, sizeof(view));
     for (int k = 0; k < 3; ++k) {
         view.cam_o[k] = (R)sc->camera.origin[k];
@@ -370,7 +400,8 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view, rrt
     if (sizeof(R) == 4) {  // magnitudes for the error bounds of tracked f32 queries (rrt_device.hpp, HitTrack), rounded up
         std::vector<rrt::ErrRec> err(prims.size());
         auto up = [](double x) { return std::nextafterf((float)x, INFINITY) * 1.000001f; };
-        for (size_t i = 0; i < prims.size(); ++i) {
+        run_in_shares(prims.size(), n_threads, [&](int, size_t b0, size_t e0) {
+          for (size_t i = b0; i < e0; ++i) {
             const double* f = prims[i].f;
             auto sum3 = [&](int k) { return std::fabs(f[k]) + std::fabs(f[k + 1]) + std::fabs(f[k + 2]); };
             rrt::ErrRec e;
@@ -392,14 +423,18 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view, rrt
                 }
             }
             err[i] = e;
-        }
+          }
+        });
+        lap("magnitudes");
         if ((rc = upload(ds, err, &ds->err32, stream)) != RRT_OK) return rc;
+        lap("magnitudes uploaded");
     }
     if ((rc = upload(ds, p, &view.prims, stream)) != RRT_OK) return rc;
     if ((rc = upload(ds, s, &view.shade, stream)) != RRT_OK) return rc;
     if ((rc = upload(ds, m, &view.mats, stream)) != RRT_OK) return rc;
     view.n_prims = (int32_t)prims.size();
     view.n_objects = (int32_t)mats.size();
+    lap("records uploaded");
     std::vector<int32_t> runs;  // maximal runs of equal record type, in scan order
     for (size_t i = 0; i < prims.size(); ++i) {
         if (i == 0 || prims[i].type != prims[i - 1].type) {
@@ -412,21 +447,37 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view, rrt
     }
     // parallelogram and triangle runs, and sphere and plane runs of more than one, two records side by side
     std::vector<rrt::PairRec<R>> pairs;
-    for (size_t r = 0; r < runs.size(); r += 4) {
-        const bool round = runs[r] == rrt::PRIM_SPHERE || runs[r] == rrt::PRIM_PLANE;
-        if (runs[r] == rrt::PRIM_QUAD || (round && runs[r + 2] < 2)) continue;
-        runs[r + 3] = (int32_t)pairs.size();
-        for (int k = 0; k < runs[r + 2]; k += 2) {
-            rrt::PairRec<R> pr;
-            std::memset(&pr, 0, sizeof(pr));
-            // the pad of an odd run must be missed by every ray: n = 0 does that for the plane forms, a sphere
-            // needs radius^2 < 0 (with radius^2 = 0 a ray through its centre would hit it)
-            if (runs[r] == rrt::PRIM_SPHERE) pr.g[4][1] = (R)-1;
-            for (int h = 0; h < 2 && k + h < runs[r + 2]; ++h)
-                for (int j = 0; j < 12; ++j) pr.g[j][h] = p[(size_t)runs[r + 1] + k + h].f[j];
-            pairs.push_back(pr);
+    {
+        size_t n_pairs = 0;
+        for (size_t r = 0; r < runs.size(); r += 4) {
+            const bool round = runs[r] == rrt::PRIM_SPHERE || runs[r] == rrt::PRIM_PLANE;
+            if (runs[r] == rrt::PRIM_QUAD || (round && runs[r + 2] < 2)) continue;
+            runs[r + 3] = (int32_t)n_pairs;
+            n_pairs += (size_t)(runs[r + 2] + 1) / 2;
+        }
+        pairs.resize(n_pairs);
+        for (size_t r = 0; r < runs.size(); r += 4) {
+            const bool round = runs[r] == rrt::PRIM_SPHERE || runs[r] == rrt::PRIM_PLANE;
+            if (runs[r] == rrt::PRIM_QUAD || (round && runs[r + 2] < 2)) continue;
+            const int type = runs[r], first = runs[r + 1], count = runs[r + 2];
+            rrt::PairRec<R>* out = pairs.data() + runs[r + 3];
+            const size_t in_run = (size_t)(count + 1) / 2;
+            run_in_shares(in_run, share_threads(in_run), [&](int, size_t b, size_t e) {
+                for (size_t q = b; q < e; ++q) {
+                    const int k = (int)(2 * q);
+                    rrt::PairRec<R> pr;
+                    std::memset(&pr, 0, sizeof(pr));
+                    // the pad of an odd run must be missed by every ray: n = 0 does that for the plane forms, a sphere
+                    // needs radius^2 < 0 (with radius^2 = 0 a ray through its centre would hit it)
+                    if (type == rrt::PRIM_SPHERE) pr.g[4][1] = (R)-1;
+                    for (int h = 0; h < 2 && k + h < count; ++h)
+                        for (int j = 0; j < 12; ++j) pr.g[j][h] = p[(size_t)first + (size_t)(k + h)].f[j];
+                    out[q] = pr;
+                }
+            });
         }
     }
+    lap("pairs made");
     if ((rc = upload(ds, runs, &view.runs, stream)) != RRT_OK) return rc;
     if ((rc = upload(ds, pairs, &view.pairs, stream)) != RRT_OK) return rc;
     view.n_runs = (int32_t)(runs.size() / 4);
@@ -440,6 +491,7 @@ int fill_view(DeviceScene* ds, const rrt_scene* sc, rrt::SceneView<R>& view, rrt
     lview.n = (int32_t)lights.size();
     ds->n_unbounded_lights = hl.n_unbounded;
     HIP_TRY(hipStreamSynchronize(stream));  // the staging vectors die here
+    lap("all uploaded");
     return RRT_OK;
 }
 
@@ -455,13 +507,21 @@ int device_scene(rrt_backend* be, const rrt_scene* sc_const, DeviceScene** out) 
     DeviceScene* ds = new (std::nothrow) DeviceScene();
     if (!ds) return fail(RRT_ERR_NOMEM, "out of host memory");
     ds->device = be->device;
+    static const bool print_times = getenv("RRT_DEBUG_BUILD_TIMES") != nullptr;  // developer switch: phases to stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&t_begin]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     std::vector<rrt::PrimRec<double>> prims(sc->prims.size());
     std::vector<rrt::ShadeRec<double>> shade(sc->prims.size());
     std::vector<rrt::MatRec<double>> mats(sc->materials.size());
-    for (size_t i = 0; i < sc->prims.size(); ++i) prepare_prim(sc->prims[i], prims[i], shade[i]);
+    run_in_shares(sc->prims.size(), share_threads(sc->prims.size()), [&](int, size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) prepare_prim(sc->prims[i], prims[i], shade[i]);
+    });
     for (size_t i = 0; i < sc->materials.size(); ++i) prepare_material(sc->materials[i], mats[i]);
+    if (print_times) fprintf(stderr, "[rrt] scene tables: records of %zu primitives at %.1f ms\n", sc->prims.size(), since());
     int rc = fill_view<float>(ds, sc, ds->v32, ds->l32, prims, shade, mats, be->stream);
+    if (print_times) fprintf(stderr, "[rrt] scene tables: f32 view at %.1f ms\n", since());
     if (rc == RRT_OK) rc = fill_view<double>(ds, sc, ds->v64, ds->l64, prims, shade, mats, be->stream);
+    if (print_times) fprintf(stderr, "[rrt] scene tables: f64 view at %.1f ms\n", since());
     if (rc != RRT_OK) {
         delete ds;
         return rc;
@@ -578,23 +638,8 @@ int ensure_bvh(rrt_backend* be, const rrt_scene* sc, DeviceScene* ds, int kind, 
     static const bool print_times = getenv("RRT_DEBUG_BUILD_TIMES") != nullptr;  // developer switch: phases to stderr
     auto since = [&t_begin]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     const size_t n_all = sc->prims.size();
-    const int n_threads = n_all < 20000 ? 1 : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    // fn(thread, begin, end) over [0, count) in contiguous shares; falls back to the calling thread when no thread can be had
-    auto in_shares = [n_threads](size_t count, const std::function<void(int, size_t, size_t)>& fn) {
-        std::vector<std::thread> pool;
-        const size_t per = (count + (size_t)n_threads - 1) / (size_t)n_threads;
-        int started = 1;
-        try {
-            for (; started < n_threads; ++started) {
-                const size_t b = std::min(count, per * (size_t)started), e = std::min(count, b + per);
-                pool.emplace_back(fn, started, b, e);
-            }
-        } catch (const std::system_error&) {
-        }
-        fn(0, 0, std::min(count, per));
-        for (std::thread& t : pool) t.join();
-        if (started < n_threads) fn(started, std::min(count, per * (size_t)started), count);  // what the missing threads would have done
-    };
+    const int n_threads = share_threads(n_all);
+    auto in_shares = [n_threads](size_t count, const std::function<void(int, size_t, size_t)>& fn) { run_in_shares(count, n_threads, fn); };
     std::vector<uint8_t> outside(n_all);
     double scale = 0;
     try {
