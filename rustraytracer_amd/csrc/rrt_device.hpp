@@ -414,6 +414,8 @@ struct HitTrack<true> {
     float best_err;  // error bound of the closest distance found so far
     float last_err;  // error bound of the distance the last primitive test reported
     float ku;
+    float u1;        // 1.25 u: one rounding, with the margin for second-order terms
+    float e_in;      // error of the ray's components in units of u (0: the ray IS f32; 1: rounded from f64)
     float om;        // |o|_inf of the ray
     const ErrRec* err;  // the scene's magnitudes, scan order
 };
@@ -422,6 +424,8 @@ RRT_DEV void track_start(HitTrack<true>& tr, const ErrRec* err, V3<float> o, flo
     tr.amb = false;
     tr.best_err = tr.last_err = 0.f;
     tr.ku = 1.25f * (5.f + e_in) * 5.9604644775390625e-8f;
+    tr.u1 = 1.25f * 5.9604644775390625e-8f;
+    tr.e_in = e_in;
     tr.om = fmaxf(fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
 }
 RRT_DEV void track_accept(HitTrack<true>& tr) { tr.best_err = tr.last_err; }
@@ -450,19 +454,23 @@ RRT_DEV void track_judge(HitTrack<true>& tr, float fold, float nd, float det_ok,
 RRT_DEV void sphere_track(HitTrack<true>& tr, const float RRT_CONSTANT* f, const float RRT_CONSTANT* e, V3<float> o, V3<float> d,
                           float x, float d2, float t0, float best_t) {
 #pragma clang fp contract(off)
-    const float ku = tr.ku;
+    // Rounding by rounding (u1 = 1.25 u per rounding): the centre is the f64 centre rounded (u |c|), the origin carries
+    // e_in u |o|, the subtraction one more rounding of l; t_ca = l . d is three products of a component of l with one of
+    // d (|d_i| <= 1, d itself e_in u off) and two sums; q = l - t_ca d; d2 = |q|^2; x = r^2 - d2 with r^2 rounded.
+    const float u1 = tr.u1, e_in = tr.e_in;
     const float lx = f[0] - o.x, ly = f[1] - o.y, lz = f[2] - o.z;
     const float l1 = __builtin_fabsf(lx) + __builtin_fabsf(ly) + __builtin_fabsf(lz);
     const float t_ca = lz * d.z + (ly * d.y + lx * d.x);
-    const float el = ku * (e[0] + tr.om);                  // error of a component of l = c - o
-    const float e_tca = 3.f * el + ku * l1;
-    const float e_q = el + e_tca + ku * (l1 + __builtin_fabsf(t_ca));  // of a component of q = l - t_ca d
+    const float el = u1 * (2.f * e[0] + (1.f + e_in) * tr.om);            // error of a component of l = c - o
+    const float e_tca = 3.f * el + u1 * (3.f + e_in) * l1;
+    const float e_q = el + e_tca + u1 * (l1 + (2.f + e_in) * __builtin_fabsf(t_ca));  // of a component of q = l - t_ca d
     const float q1 = 1.7320508f * __builtin_amdgcn_sqrtf(d2);           // >= |q|_1
-    const float e_x = 2.f * q1 * e_q + ku * (d2 + f[4]);
+    // (f64 forms d2 as |l|^2 - t_ca^2, which is |l - t_ca d|^2 only for a unit d; an f32 direction is unit to a few u)
+    const float e_x = 2.f * q1 * e_q + u1 * (4.f * d2 + 2.f * f[4] + 8.f * t_ca * t_ca);
     if (x < -e_x) { tr.last_err = 0.f; return; }           // misses beyond doubt
     if (!(x > e_x)) { tr.amb = true; return; }
     const float t_hc = __builtin_amdgcn_sqrtf(x);
-    const float e_t0 = e_tca + e_x * __builtin_amdgcn_rcpf(t_hc) + ku * (__builtin_fabsf(t_ca) + t_hc);
+    const float e_t0 = e_tca + e_x * __builtin_amdgcn_rcpf(t_hc) + 2.f * u1 * (__builtin_fabsf(t_ca) + t_hc);
     tr.last_err = e_t0;
     const float ta = t_ca - t_hc;
     const float fold = fminf(t0 - Num<float>::tmin(), best_t - t0);
