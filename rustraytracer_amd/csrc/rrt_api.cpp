@@ -1154,6 +1154,19 @@ int render_wavefront(rrt_backend* be, const rrt::SceneView<R>& sv, const rrt::Li
     return RRT_OK;
 }
 
+// What an exception caught at the C ABI turns into (called from a catch block).
+int exception_status() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        return fail(RRT_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(RRT_ERR_HIP, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(RRT_ERR_HIP, "internal error");
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1161,7 +1174,7 @@ extern "C" {
 const char* rrt_last_error(void) { return g_last_error.c_str(); }
 
 int rrt_camera_perspective(const double look_from[3], const double look_at[3], const double vup[3],
-                           double vfov_deg, double aspect, rrt_camera* out) {
+                           double vfov_deg, double aspect, rrt_camera* out) try {
     if (!look_from || !look_at || !vup || !out) return fail(RRT_ERR_INVALID, "NULL argument");
     const double PI = 3.14159265358979323846264338327950288;
     double theta = vfov_deg * PI / 180.0;
@@ -1178,9 +1191,11 @@ int rrt_camera_perspective(const double look_from[3], const double look_at[3], c
     out->horizontal[0] = h.x; out->horizontal[1] = h.y; out->horizontal[2] = h.z;
     out->vertical[0] = ve.x; out->vertical[1] = ve.y; out->vertical[2] = ve.z;
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
-int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
+int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) try {
     if (!desc || !out) return fail(RRT_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (desc->n_prims && !desc->prims) return fail(RRT_ERR_INVALID, "prims is NULL");
@@ -1205,6 +1220,8 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     sc->materials.assign(desc->materials, desc->materials + desc->n_objects);
     *out = sc;
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 void rrt_scene_destroy(rrt_scene* scene) {
@@ -1213,7 +1230,7 @@ void rrt_scene_destroy(rrt_scene* scene) {
     delete scene;
 }
 
-int rrt_backend_create(const char* name, int device_id, rrt_backend** out) {
+int rrt_backend_create(const char* name, int device_id, rrt_backend** out) try {
     if (!name || !out) return fail(RRT_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (std::strcmp(name, "hip") != 0)
@@ -1253,6 +1270,8 @@ int rrt_backend_create(const char* name, int device_id, rrt_backend** out) {
     }
     *out = be;
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 void rrt_backend_destroy(rrt_backend* be) {
@@ -1265,24 +1284,30 @@ void rrt_backend_destroy(rrt_backend* be) {
     delete be;
 }
 
-int rrt_backend_set_stream(rrt_backend* be, void* hip_stream) {
+int rrt_backend_set_stream(rrt_backend* be, void* hip_stream) try {
     if (!be) return fail(RRT_ERR_INVALID, "backend is NULL");
     be->stream = (hipStream_t)hip_stream;
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 int rrt_intersect(rrt_backend* be, const rrt_scene* scene, uint32_t precision, uint32_t accel, size_t n,
-                  const double* origins, const double* dirs, int32_t* object_id, int32_t* prim_id, double* t) {
+                  const double* origins, const double* dirs, int32_t* object_id, int32_t* prim_id, double* t) try {
     return closest_hit_call(be, scene, precision, accel, false, n, origins, dirs, object_id, prim_id, t);
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 int rrt_trace_primary(rrt_backend* be, const rrt_scene* scene, uint32_t precision, uint32_t accel, size_t n,
-                      const double* u, const double* v, int32_t* object_id, int32_t* prim_id, double* t) {
+                      const double* u, const double* v, int32_t* object_id, int32_t* prim_id, double* t) try {
     return closest_hit_call(be, scene, precision, accel, true, n, u, v, object_id, prim_id, t);
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t precision, uint32_t accel, size_t n,
-                         const double* origins, const double* dirs, int32_t* object_id, int32_t* prim_id, double* t) {
+                         const double* origins, const double* dirs, int32_t* object_id, int32_t* prim_id, double* t) try {
     int rc = check_backend(be);
     if (rc != RRT_OK) return rc;
     if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
@@ -1328,10 +1353,12 @@ int rrt_intersect_static(rrt_backend* be, const rrt_scene* scene, uint32_t preci
     HIP_TRY(hipMemcpyAsync(t, sp->t, n * sizeof(double), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipStreamSynchronize(be->stream));
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_render_desc* desc,
-                          float* rgb_sum, rrt_stats* stats) {
+                          float* rgb_sum, rrt_stats* stats) try {
     int rc = check_backend(be);
     if (rc != RRT_OK) return rc;
     if (!scene) return fail(RRT_ERR_INVALID, "scene is NULL");
@@ -1431,9 +1458,11 @@ int rrt_render_accumulate(rrt_backend* be, const rrt_scene* scene, const rrt_ren
         stats->exact_redos = counters[rrt::COUNTER_EXACT_REDOS];
     }
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
-int rrt_sampler_values(rrt_backend* be, const rrt_render_desc* desc, uint32_t pixel, float* out_host) {
+int rrt_sampler_values(rrt_backend* be, const rrt_render_desc* desc, uint32_t pixel, float* out_host) try {
     int rc = check_backend(be);
     if (rc != RRT_OK) return rc;
     if (!out_host) return fail(RRT_ERR_INVALID, "out is NULL");
@@ -1447,10 +1476,12 @@ int rrt_sampler_values(rrt_backend* be, const rrt_render_desc* desc, uint32_t pi
     HIP_TRY(hipMemcpyAsync(out_host, buf.p, bytes, hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipStreamSynchronize(be->stream));
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 int rrt_material_probe(rrt_backend* be, const rrt_material* material, uint32_t precision, size_t n, const double* d_in,
-                       const double* normal, const double* u, double* d_out, double* weight, int32_t* ok) {
+                       const double* normal, const double* u, double* d_out, double* weight, int32_t* ok) try {
     int rc = check_backend(be);
     if (rc != RRT_OK) return rc;
     if (!material) return fail(RRT_ERR_INVALID, "material is NULL");
@@ -1479,10 +1510,12 @@ int rrt_material_probe(rrt_backend* be, const rrt_material* material, uint32_t p
     HIP_TRY(hipMemcpyAsync(ok, d_ok, n * sizeof(int32_t), hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipStreamSynchronize(be->stream));
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 int rrt_postprocess(rrt_backend* be, const float* rgb_sum, uint64_t spp_divisor, const rrt_post_desc* post,
-                    uint32_t width, uint32_t height, uint8_t* rgb8) {
+                    uint32_t width, uint32_t height, uint8_t* rgb8) try {
     int rc = check_backend(be);
     if (rc != RRT_OK) return rc;
     if (!rgb_sum || !post || !rgb8) return fail(RRT_ERR_INVALID, "NULL argument");
@@ -1516,10 +1549,12 @@ int rrt_postprocess(rrt_backend* be, const float* rgb_sum, uint64_t spp_divisor,
     if (!out_dev) HIP_TRY(hipMemcpyAsync(rgb8, d_out, n, hipMemcpyDeviceToHost, be->stream));
     HIP_TRY(hipStreamSynchronize(be->stream));
     return RRT_OK;
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 int rrt_render(rrt_backend* be, const rrt_scene* scene, const rrt_render_desc* desc, const rrt_post_desc* post,
-               uint8_t* rgb8_host, rrt_stats* stats) {
+               uint8_t* rgb8_host, rrt_stats* stats) try {
     int rc = check_backend(be);
     if (rc != RRT_OK) return rc;
     if (!desc || !post || !rgb8_host) return fail(RRT_ERR_INVALID, "NULL argument");
@@ -1533,6 +1568,8 @@ int rrt_render(rrt_backend* be, const rrt_scene* scene, const rrt_render_desc* d
     HIP_TRY(hipMemsetAsync(accum.p, 0, n * sizeof(float), be->stream));
     if ((rc = rrt_render_accumulate(be, scene, &d, (float*)accum.p, stats)) != RRT_OK) return rc;
     return rrt_postprocess(be, (const float*)accum.p, d.spp, post, d.width, d.height, rgb8_host);
+} catch (...) {
+    return exception_status();  // nothing may unwind through the C ABI
 }
 
 }  // extern "C"
