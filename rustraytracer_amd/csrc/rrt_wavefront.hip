@@ -658,7 +658,7 @@ void launch_tree_walk(const SceneView<float>& sv, const WfParams<float>& wp, int
     static const int refill_min = [] { const char* e = getenv("RRT_DEBUG_REFILL_MIN"); return e ? atoi(e) : WF_REFILL_MIN; }();  // experiments
     hipLaunchKernelGGL(wf_closest_hit_tree, dim3(want), dim3(BVH_BLOCK), 0, stream, sv, wp, parity, refill_min, sh);
 }
-// f64 (checks against the oracle): one ray per lane from start to end, the walk the parity kernels use
+// f64 (the checking mode): one ray per lane from start to end, the walk the parity kernels use
 void launch_tree_walk(const SceneView<double>& sv, const WfParams<double>& wp, int parity, int sh, int, uint32_t grid_x, hipStream_t stream) {
     hipLaunchKernelGGL((wf_closest_hit<double, true>), dim3(grid_x), dim3(WF_HIT_BLOCK), 0, stream, sv, wp, parity, sh);
 }

@@ -15,7 +15,7 @@
 namespace rrt {
 
 // Element types of the queues in the arithmetic type of the render: f32 is the product path; f64 (the reference's
-// type, for checking the pipeline against the oracle path by path) takes twice the bytes.  The fourth component of a
+// type, for checking the pipeline path by path against a CPU statement of the reference) takes twice the bytes.  The fourth component of a
 // 4-vector and the second of a 2-vector carry integers as bit patterns.
 template <typename R> struct WfElem;
 template <> struct WfElem<float> {
